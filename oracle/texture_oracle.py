@@ -1,0 +1,358 @@
+"""CPU oracle for the texture/noise hot path — TEST INFRASTRUCTURE ONLY.
+
+Two things live here:
+
+* ``COracle`` — a ctypes binding of ``oracle/libtexture_oracle.so`` (the C
+  restatement in ``texture_oracle.c``).
+* ``np_*`` — a second, independent restatement in numpy/scipy that shares no
+  code with the C one.  Integer stages of the two must agree bit for bit
+  (``tests/test_oracle.py``); that double implementation is the only check
+  available for the OpenCV stages, which are PARITY UNPINNED (no OpenCV offline,
+  no fixtures in the reference).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+may import this module.  The product package ``sift_amd`` never does.
+
+Follows /root/reference/app/passive_checker.py:96-164.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libtexture_oracle.so")
+
+LBP_MAX_BINS = 26
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("lbp_points", C.c_int),
+        ("lbp_radius", C.c_double),
+        ("canny_low", C.c_int),
+        ("canny_high", C.c_int),
+        ("gray_shift", C.c_int),
+        ("fft_h", C.c_int),
+        ("fft_w", C.c_int),
+    ]
+
+
+class OrcMetrics(C.Structure):
+    _fields_ = [
+        ("lbp_variance", C.c_double),
+        ("noise_level", C.c_double),
+        ("compression_artifacts", C.c_double),
+        ("edge_density", C.c_double),
+        ("frequency_anomaly", C.c_double),
+        ("texture_score", C.c_double),
+        ("lbp_hist", C.c_uint32 * LBP_MAX_BINS),
+        ("edge_count", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("absdiff_sum", C.c_uint64),
+        ("hp_sum", C.c_uint64),
+        ("hp_sumsq", C.c_uint64),
+        ("gray_sum", C.c_uint64),
+        ("n_pixels", C.c_uint64),
+        ("fft_sum", C.c_double),
+        ("fft_sumsq", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc if the shared object is missing or stale."""
+    src = os.path.join(_HERE, "texture_oracle.c")
+    hdr = os.path.join(_HERE, "texture_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB)
+        or (os.path.exists(src) and os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    )
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libtexture_oracle.so"])
+    return _LIB
+
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_u8p)
+
+
+class COracle:
+    """ctypes view of the C restatement."""
+
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+        L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, C.c_int64, C.c_int, _u8p]
+        L.orc_lbp_offsets.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_lbp_uniform.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.POINTER(C.c_uint32)]
+        L.orc_highpass3.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
+        L.orc_gauss5.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
+        L.orc_canny.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+        L.orc_fft_logmag_stats.argtypes = [
+            _u8p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_analyze_frame.argtypes = [_u8p, C.c_int, C.c_int, C.c_int64, C.POINTER(OrcParams), C.POINTER(OrcMetrics)]
+        L.orc_synth_frame.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _u8p]
+        L.orc_texture_score.argtypes = [C.POINTER(OrcMetrics)]
+        L.orc_texture_score.restype = C.c_double
+
+    def default_params(self) -> OrcParams:
+        p = OrcParams()
+        self.lib.orc_default_params(C.byref(p))
+        return p
+
+    def gray(self, bgr: np.ndarray, shift: int = 14) -> np.ndarray:
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, _ = bgr.shape
+        out = np.empty((h, w), np.uint8)
+        self.lib.orc_bgr2gray(_p(bgr), h, w, w * 3, shift, _p(out))
+        return out
+
+    def lbp_offsets(self, P: int, R: float):
+        rp = (C.c_double * 24)()
+        cp = (C.c_double * 24)()
+        if self.lib.orc_lbp_offsets(P, R, rp, cp) != 0:
+            raise ValueError("bad P")
+        return np.array(rp[:P]), np.array(cp[:P])
+
+    def lbp(self, gray: np.ndarray, P: int = 8, R: float = 1.0):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        codes = np.empty((h, w), np.uint8)
+        hist = (C.c_uint32 * LBP_MAX_BINS)()
+        if self.lib.orc_lbp_uniform(_p(gray), h, w, P, R, _p(codes), hist) != 0:
+            raise ValueError("bad P")
+        return codes, np.array(hist[: P + 2], dtype=np.uint32)
+
+    def highpass(self, gray: np.ndarray) -> np.ndarray:
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        out = np.empty_like(gray)
+        self.lib.orc_highpass3(_p(gray), gray.shape[0], gray.shape[1], _p(out))
+        return out
+
+    def gauss5(self, gray: np.ndarray) -> np.ndarray:
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        out = np.empty_like(gray)
+        self.lib.orc_gauss5(_p(gray), gray.shape[0], gray.shape[1], _p(out))
+        return out
+
+    def canny(self, gray: np.ndarray, low: int = 50, high: int = 150):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        edges = np.empty_like(gray)
+        nms = np.empty_like(gray)
+        cnt = self.lib.orc_canny(_p(gray), gray.shape[0], gray.shape[1], low, high, _p(edges), _p(nms))
+        if cnt < 0:
+            raise MemoryError
+        return edges, nms, cnt
+
+    def fft_stats(self, gray: np.ndarray, want_spectrum: bool = False):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        s = C.c_double()
+        s2 = C.c_double()
+        spec = np.empty((h, w, 2), np.float64) if want_spectrum else None
+        sp = spec.ctypes.data_as(C.POINTER(C.c_double)) if want_spectrum else None
+        if self.lib.orc_fft_logmag_stats(_p(gray), h, w, w, C.byref(s), C.byref(s2), sp) != 0:
+            raise MemoryError
+        return s.value, s2.value, (spec[..., 0] + 1j * spec[..., 1] if want_spectrum else None)
+
+    def analyze_frame(self, bgr: np.ndarray, params: OrcParams | None = None) -> OrcMetrics:
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, c = bgr.shape
+        assert c == 3
+        m = OrcMetrics()
+        rc = self.lib.orc_analyze_frame(_p(bgr), h, w, w * 3, C.byref(params) if params is not None else None, C.byref(m))
+        if rc != 0:
+            raise ValueError("orc_analyze_frame failed")
+        return m
+
+    def synth_frame(self, kind: int, seed: int, video: int, frame: int, h: int, w: int) -> np.ndarray:
+        out = np.empty((h, w, 3), np.uint8)
+        if self.lib.orc_synth_frame(kind, seed, video, frame, h, w, _p(out)) != 0:
+            raise ValueError("bad synth arguments")
+        return out
+
+
+METRIC_KEYS = ("lbp_variance", "noise_level", "compression_artifacts", "edge_density", "frequency_anomaly")
+
+
+def metrics_to_dict(m: OrcMetrics) -> dict:
+    return {k: float(getattr(m, k)) for k in METRIC_KEYS}
+
+
+# --------------------------------------------------------------------------- numpy / scipy mirror
+
+
+def np_gray(bgr: np.ndarray, shift: int = 14) -> np.ndarray:
+    """cv2.cvtColor(BGR2GRAY), passive_checker.py:100 (fixed point, round to nearest)."""
+    b = bgr[..., 0].astype(np.int64)
+    g = bgr[..., 1].astype(np.int64)
+    r = bgr[..., 2].astype(np.int64)
+    if shift == 15:
+        return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+def _pad101(a: np.ndarray, n: int) -> np.ndarray:
+    """BORDER_REFLECT_101 padding that also works when a side is shorter than n+1."""
+    def idx(length):
+        i = np.arange(-n, length + n)
+        if length == 1:
+            return np.zeros_like(i)
+        period = 2 * length - 2
+        i = np.mod(i, period)
+        return np.where(i >= length, period - i, i)
+    return a[np.ix_(idx(a.shape[0]), idx(a.shape[1]))]
+
+
+def np_highpass(gray: np.ndarray) -> np.ndarray:
+    """cv2.filter2D(gray, -1, 3x3 high-pass), passive_checker.py:107."""
+    from scipy import ndimage
+    k = np.array([[-1, -1, -1], [-1, 8, -1], [-1, -1, -1]], dtype=np.int64)
+    p = _pad101(gray.astype(np.int64), 1)
+    full = ndimage.correlate(p, k, mode="constant", cval=0)
+    return np.clip(full[1:-1, 1:-1], 0, 255).astype(np.uint8)
+
+
+def np_gauss5(gray: np.ndarray) -> np.ndarray:
+    """cv2.GaussianBlur(gray, (5,5), 0), passive_checker.py:111."""
+    w = np.array([1, 4, 6, 4, 1], dtype=np.int64)
+    p = _pad101(gray.astype(np.int64), 2)
+    h_, w_ = gray.shape
+    hor = sum(w[i] * p[:, i:i + w_] for i in range(5))
+    ver = sum(w[i] * hor[i:i + h_, :] for i in range(5))
+    return ((ver + 128) >> 8).astype(np.uint8)
+
+
+def np_canny(gray: np.ndarray, low: int = 50, high: int = 150):
+    """cv2.Canny(gray, 50, 150), passive_checker.py:116.  Returns (edges u8 0/255, nms map 0/1/2)."""
+    from scipy import ndimage
+    h, w = gray.shape
+    g = np.pad(gray.astype(np.int64), 1, mode="edge")  # BORDER_REPLICATE
+    gx = (g[:-2, 2:] - g[:-2, :-2]) + 2 * (g[1:-1, 2:] - g[1:-1, :-2]) + (g[2:, 2:] - g[2:, :-2])
+    gy = (g[2:, :-2] - g[:-2, :-2]) + 2 * (g[2:, 1:-1] - g[:-2, 1:-1]) + (g[2:, 2:] - g[:-2, 2:])
+    mag = np.abs(gx) + np.abs(gy)
+    mp = np.pad(mag, 1, mode="constant")
+
+    def nb(dy, dx):
+        return mp[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+
+    ax = np.abs(gx)
+    ay = np.abs(gy) << 15
+    tg22 = ax * 13573
+    tg67 = tg22 + (ax << 16)
+    horiz = ay < tg22
+    vert = (~horiz) & (ay > tg67)
+    diag = ~(horiz | vert)
+    opposite = (gx ^ gy) < 0
+    keep_h = (mag > nb(0, -1)) & (mag >= nb(0, 1))
+    keep_v = (mag > nb(-1, 0)) & (mag >= nb(1, 0))
+    keep_d_same = (mag > nb(-1, -1)) & (mag > nb(1, 1))
+    keep_d_opp = (mag > nb(-1, 1)) & (mag > nb(1, -1))
+    keep = (horiz & keep_h) | (vert & keep_v) | (diag & np.where(opposite, keep_d_opp, keep_d_same))
+    keep &= mag > low
+    nms = np.where(keep, np.where(mag > high, 2, 1), 0).astype(np.uint8)
+    lab, n = ndimage.label(nms > 0, structure=np.ones((3, 3), dtype=int))
+    if n:
+        has_strong = ndimage.maximum(nms, lab, index=np.arange(1, n + 1)) == 2
+        ok = np.concatenate([[False], has_strong])
+        edges = np.where(ok[lab], 255, 0).astype(np.uint8)
+    else:
+        edges = np.zeros_like(nms)
+    return edges, nms
+
+
+def np_lbp_uniform(gray: np.ndarray, P: int = 8, R: float = 1.0) -> np.ndarray:
+    """skimage.feature.local_binary_pattern(gray, P, R, 'uniform'), passive_checker.py:103.
+
+    Vectorised over the image; every fp64 operation is the same single
+    numpy ufunc call the scalar algorithm performs, in the same order.
+    """
+    h, w = gray.shape
+    img = gray.astype(np.float64)
+    ang = 2 * np.pi * np.arange(P, dtype=np.double) / P
+    rp = np.round(-R * np.sin(ang), 5)
+    cp = np.round(R * np.cos(ang), 5)
+    rr = np.arange(h, dtype=np.float64)[:, None]
+    cc = np.arange(w, dtype=np.float64)[None, :]
+    pad = int(np.ceil(R)) + 1
+    z = np.zeros((h + 2 * pad, w + 2 * pad), np.float64)
+    z[pad:pad + h, pad:pad + w] = img
+
+    def at(ri, ci):
+        return z[ri + pad, ci + pad]
+
+    bits = np.empty((P, h, w), np.int8)
+    for i in range(P):
+        rf = rr + rp[i]
+        cf = cc + cp[i]
+        minr = np.floor(rf); maxr = np.ceil(rf)
+        minc = np.floor(cf); maxc = np.ceil(cf)
+        dr = rf - minr
+        dc = cf - minc
+        minr_i = np.broadcast_to(minr.astype(np.int64), (h, w)); maxr_i = np.broadcast_to(maxr.astype(np.int64), (h, w))
+        minc_i = np.broadcast_to(minc.astype(np.int64), (h, w)); maxc_i = np.broadcast_to(maxc.astype(np.int64), (h, w))
+        tl = at(minr_i, minc_i); tr = at(minr_i, maxc_i)
+        bl = at(maxr_i, minc_i); br = at(maxr_i, maxc_i)
+        top = (1 - dc) * tl + dc * tr
+        bottom = (1 - dc) * bl + dc * br
+        t = (1 - dr) * top + dr * bottom
+        bits[i] = (t - img) >= 0
+    changes = (bits[:-1] != bits[1:]).sum(axis=0)
+    ones = bits.sum(axis=0)
+    return np.where(changes <= 2, ones, P + 1).astype(np.uint8)
+
+
+def np_analyze_frame(bgr: np.ndarray, P: int = 8, R: float = 1.0, low: int = 50, high: int = 150,
+                     shift: int = 14) -> dict:
+    """The five metrics of passive_checker.py:96-131 with numpy doing every reduction the reference gives it."""
+    gray = np_gray(bgr, shift)
+    lbp = np_lbp_uniform(gray, P, R).astype(np.float64)
+    hf = np_highpass(gray)
+    blur = np_gauss5(gray)
+    diff = np.abs(gray.astype(np.int16) - blur.astype(np.int16)).astype(np.uint8)
+    edges, _ = np_canny(gray, low, high)
+    mag = np.log(np.abs(np.fft.fftshift(np.fft.fft2(gray))) + 1)
+    return {
+        "lbp_variance": float(np.var(lbp)),
+        "noise_level": float(np.std(hf)),
+        "compression_artifacts": float(np.mean(diff)),
+        "edge_density": float(np.sum(edges > 0) / edges.size),
+        "frequency_anomaly": float(np.std(mag)),
+    }
+
+
+def np_texture_score(m: dict) -> float:
+    """passive_checker.py:145-151."""
+    return (
+        min(m["lbp_variance"] / 50.0, 1.0) * 0.3
+        + min(m["edge_density"] * 10, 1.0) * 0.2
+        + (1.0 - min(m["compression_artifacts"] / 10.0, 1.0)) * 0.2
+        + min(m["noise_level"] / 20.0, 1.0) * 0.15
+        + (1.0 - min(m["frequency_anomaly"] / 100.0, 1.0)) * 0.15
+    )
+
+
+def np_compute_texture_score(frames, threshold: float = 0.6, **kw) -> dict:
+    """passive_checker.py:133-164."""
+    scores, detailed = [], []
+    for frame in frames[:10]:
+        m = np_analyze_frame(frame, **kw)
+        detailed.append(m)
+        scores.append(np_texture_score(m))
+    avg = np.mean(scores) if scores else 0.0
+    passed = avg >= threshold
+    return {
+        "passed": bool(passed),
+        "average_score": round(float(avg), 3),
+        "individual_scores": [round(float(s), 3) for s in scores],
+        "detailed_metrics": detailed,
+        "message": f"Texture analysis {'passed' if passed else 'failed'} (score: {avg:.3f})",
+    }

@@ -1,0 +1,29 @@
+"""Case lists shared by the golden generators and the tests (pure data)."""
+
+SEED = 0x5EED0000
+
+# (kind, h, w) images used for the LBP goldens; gray = G channel of the synthetic frame
+LBP_IMAGES = [
+    ("noise", 24, 31), ("tie", 24, 31), ("ramp", 24, 31), ("flat", 24, 31), ("natural", 24, 31), ("step", 24, 31),
+    ("noise", 40, 40), ("tie", 40, 40), ("natural", 40, 40),
+    ("noise", 64, 64), ("step", 64, 64), ("ramp", 64, 64),
+    ("natural", 80, 80), ("tie", 80, 80),
+    ("natural", 256, 256),
+    ("noise", 1, 1), ("noise", 1, 9), ("noise", 7, 1), ("noise", 2, 3), ("tie", 3, 70),
+]
+LBP_PR = [(8, 1.0), (16, 2.0), (24, 3.0)]
+
+# (kind, h, w) for the FFT statistic goldens (numpy 2.2.6)
+FFT_IMAGES = [
+    ("noise", 24, 31), ("natural", 40, 40), ("noise", 64, 64), ("natural", 80, 80), ("step", 90, 120),
+    ("natural", 256, 256), ("noise", 17, 23), ("noise", 1, 1), ("noise", 1, 16), ("noise", 12, 1),
+    ("ramp", 48, 36), ("flat", 16, 16), ("natural", 45, 80), ("noise", 2, 2), ("tie", 14, 22),
+]
+
+# frame sets for the whole-path goldens: (name, kind, n_frames, h, w)
+SCORE_SETS = [
+    ("noise64", "noise", 10, 64, 64), ("natural64", "natural", 10, 64, 64), ("step64", "step", 10, 64, 64),
+    ("tie64", "tie", 3, 64, 64), ("ramp64", "ramp", 2, 64, 64), ("flat64", "flat", 1, 64, 64),
+    ("natural_12frames", "natural", 12, 48, 80), ("empty", "noise", 0, 64, 64),
+    ("natural_odd", "natural", 4, 45, 77),
+]
