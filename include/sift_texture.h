@@ -1,0 +1,142 @@
+/*
+ * sift_texture.h — C ABI of libsift_texture.so, the MI355X (gfx950) implementation of
+ * the texture/noise hot path of y-mitsuyoshi/sift.
+ *
+ * The reference has no FFI for this path: the boundary is the Python class
+ * TextureNoiseDetector (/root/reference/app/passive_checker.py:88-164).  These entry
+ * points are what a ctypes binding of that class calls; sift_amd/texture.py is such a
+ * binding.  Every function returns STX_OK (0) or a negative error code, never throws,
+ * never aborts; stx_last_error() gives the message for the last failure on a context.
+ *
+ * Frame layout everywhere: uint8, BGR interleaved, [H][W][3], the layout
+ * extract_frames() produces (/root/reference/app/video_processor.py:18-49).
+ */
+#ifndef SIFT_TEXTURE_H
+#define SIFT_TEXTURE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STX_OK 0
+#define STX_ERR_INVALID (-1)     /* bad argument */
+#define STX_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define STX_ERR_UNSUPPORTED (-3) /* size or parameter outside what the kernels handle */
+#define STX_ERR_NOMEM (-4)
+
+#define STX_LBP_MAX_BINS 26 /* P + 2 bins, P <= 24 */
+#define STX_MAX_DIM 8192    /* largest frame height or width */
+
+typedef struct stx_ctx stx_ctx;
+
+/* Parameters of analyze_frame; the defaults (stx_default_params) are the literals in
+ * passive_checker.py:100-123. */
+typedef struct stx_params {
+    int lbp_points;    /* P, default 8      (passive_checker.py:103) */
+    double lbp_radius; /* R, default 1.0    (passive_checker.py:103) */
+    int canny_low;     /* default 50        (passive_checker.py:116) */
+    int canny_high;    /* default 150       (passive_checker.py:116) */
+    int gray_shift;    /* 14 (default) or 15: fixed-point width of the BGR->gray weights (:100) */
+    int fft_h, fft_w;  /* 0,0 (default) = transform the whole frame (:120); else a centred crop */
+} stx_params;
+
+/* Per-frame result: the five metrics of passive_checker.py:125-131, the per-frame score
+ * of :145-151, and the integer reductions they are computed from (bit-exact quantities). */
+typedef struct stx_metrics {
+    double lbp_variance;          /* np.var(lbp)            :104 */
+    double noise_level;           /* np.std(high_freq)      :108 */
+    double compression_artifacts; /* np.mean(absdiff)       :113 */
+    double edge_density;          /* count(edges>0)/size    :117 */
+    double frequency_anomaly;     /* np.std(log|F|+1)       :123 */
+    double texture_score;         /* weighted sum           :145-151 */
+    uint32_t lbp_hist[STX_LBP_MAX_BINS]; /* histogram of uniform LBP codes 0..P+1 */
+    uint32_t edge_count;          /* Canny edge pixels */
+    uint32_t reserved;
+    uint64_t absdiff_sum;         /* sum |gray - GaussianBlur5x5(gray)| */
+    uint64_t hp_sum;              /* sum of the saturated 3x3 high-pass image */
+    uint64_t hp_sumsq;            /* sum of its squares */
+    uint64_t gray_sum;            /* sum of the gray image */
+    uint64_t n_pixels;            /* H*W */
+    double fft_sum, fft_sumsq;    /* sum, sum of squares of ln(|F|+1) over all FFT bins */
+} stx_metrics;
+
+/* Accumulated device time per kernel family, measured with HIP events on the stream
+ * the kernels run on (only while stx_set_timing(ctx, 1) is in effect). */
+#define STX_N_KERNELS 8
+typedef struct stx_timing {
+    double ms[STX_N_KERNELS];       /* total elapsed milliseconds */
+    uint64_t launches[STX_N_KERNELS]; /* kernel launches counted into ms[] */
+    uint64_t frames;                /* frames analysed while timing was on */
+} stx_timing;
+/* indices into stx_timing.ms / .launches */
+#define STX_K_GRAY 0
+#define STX_K_STENCIL 1
+#define STX_K_LBP_GENERIC 2
+#define STX_K_HYST 3
+#define STX_K_FFT_ROWS 4
+#define STX_K_FFT_COLS 5
+#define STX_K_REDUCE 6
+#define STX_K_SYNTH 7
+
+const char* stx_version(void);
+
+/* Replaces TextureNoiseDetector.__init__ (passive_checker.py:93-94): binds a context to
+ * one GPU, creates its stream and workspace.  Safe to create several per process. */
+int stx_create(int device_id, stx_ctx** out);
+int stx_destroy(stx_ctx* ctx);
+const char* stx_last_error(const stx_ctx* ctx);
+/* 1 = HIP on gfx950.  There is no CPU backend: without a usable GPU stx_create fails. */
+int stx_backend(const stx_ctx* ctx);
+void stx_default_params(stx_params* p);
+
+/* Replaces the body of analyze_frame (passive_checker.py:96-131) for n_frames frames of one
+ * size held in HOST memory (pageable or pinned).  row_stride_bytes >= 3*w; frames are
+ * frame_stride_bytes apart.  params == NULL means the reference literals.  out receives
+ * n_frames records.  The call returns after the results are on the host. */
+int stx_analyze_batch(stx_ctx* ctx, const uint8_t* bgr, int n_frames, int h, int w, int64_t row_stride_bytes,
+                      int64_t frame_stride_bytes, const stx_params* params, stx_metrics* out);
+
+/* Same, for a Python list of separately allocated frames (the loop at passive_checker.py:140-141). */
+int stx_analyze_frames(stx_ctx* ctx, const uint8_t* const* frames, int n_frames, int h, int w,
+                       int64_t row_stride_bytes, const stx_params* params, stx_metrics* out);
+
+/* Same, for frames already resident in DEVICE memory of the context's GPU (the benchmark path:
+ * no PCIe transfer in the timed region).  out is host memory. */
+int stx_analyze_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w,
+                             int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
+                             stx_metrics* out);
+
+/* compute_texture_score's reduction (passive_checker.py:145-156) over n records: mean of the
+ * per-frame scores (0.0 when n == 0) and the >= threshold verdict. */
+int stx_score_summary(const stx_metrics* m, int n, double threshold, double* average, int* passed);
+
+/* Intermediate planes for parity tests: gray (h*w), uniform LBP codes (h*w), Canny edge map
+ * (h*w, 0/255) of ONE host frame; any output pointer may be NULL. */
+int stx_debug_planes(stx_ctx* ctx, const uint8_t* bgr, int h, int w, int64_t row_stride_bytes,
+                     const stx_params* params, uint8_t* gray_out, uint8_t* lbp_codes_out, uint8_t* edges_out);
+
+/* Deterministic synthetic frames written straight into device memory (benchmark input; same
+ * integer arithmetic as sift_amd/synth.py).  kind: 0 noise, 1 natural, 2 ramp, 3 flat, 4 tie, 5 step. */
+int stx_synth_device(stx_ctx* ctx, uint8_t* bgr_dev, int kind, uint64_t seed, uint32_t video, uint32_t frame0,
+                     int n_frames, int h, int w);
+
+/* Device / pinned-host buffers for callers without their own allocator. */
+int stx_device_alloc(stx_ctx* ctx, uint64_t bytes, void** out);
+int stx_device_free(stx_ctx* ctx, void* p);
+int stx_pinned_alloc(stx_ctx* ctx, uint64_t bytes, void** out);
+int stx_pinned_free(stx_ctx* ctx, void* p);
+int stx_memcpy_d2h(stx_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+int stx_memcpy_h2d(stx_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+
+/* Frames per internal chunk (0 = choose from the frame size).  Intermediates of one chunk are
+ * sized to stay in the 256 MiB Infinity Cache. */
+int stx_set_chunk_frames(stx_ctx* ctx, int frames);
+int stx_set_timing(stx_ctx* ctx, int enabled);
+int stx_get_timing(stx_ctx* ctx, stx_timing* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

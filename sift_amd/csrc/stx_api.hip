@@ -1,0 +1,642 @@
+// Host side of libsift_texture.so: context, workspace, the per-chunk kernel schedule and
+// the scalar epilogue that turns device reductions into the five metrics of
+// TextureNoiseDetector.analyze_frame (/root/reference/app/passive_checker.py:96-131).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "stx_internal.h"
+
+using namespace stx;
+
+namespace {
+
+constexpr int HYST_MAX_PASSES = 8192;
+constexpr int HYST_GROUP = 4;  // passes issued between two host checks of the "changed" counter
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TimedSpan {
+    int kind;
+    int launches;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct stx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevBuf gray, strong, cand, spec, part, tiles, acc, changed, staging, codes, plane;
+    FrameAcc* acc_host = nullptr;  // pinned
+    size_t acc_host_cap = 0;
+    unsigned int* changed_host = nullptr;  // pinned, HYST_MAX_PASSES entries
+    std::map<int, float2*> twiddles;
+    int chunk_override = 0;
+    bool timing = false;
+    stx_timing tacc;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(stx_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return fail((c), STX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+int ensure(stx_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return STX_OK;
+    if (b.p) {
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, STX_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return STX_OK;
+}
+
+hipEvent_t get_event(stx_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// RAII-less span helpers: begin/end bracket kernel launches of one family on the context stream.
+struct Span {
+    stx_ctx* c;
+    TimedSpan t;
+    bool on;
+    Span(stx_ctx* c_, int kind, int launches) : c(c_), on(c_->timing) {
+        if (!on) return;
+        t.kind = kind;
+        t.launches = launches;
+        t.e0 = get_event(c);
+        t.e1 = get_event(c);
+        if (!t.e0 || !t.e1) { on = false; return; }
+        hipEventRecord(t.e0, c->stream);
+    }
+    void end() {
+        if (!on) return;
+        hipEventRecord(t.e1, c->stream);
+        c->spans.push_back(t);
+    }
+};
+
+void collect_spans(stx_ctx* c) {
+    for (auto& t : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            c->tacc.ms[t.kind] += ms;
+            c->tacc.launches[t.kind] += (uint64_t)t.launches;
+        }
+        c->event_pool.push_back(t.e0);
+        c->event_pool.push_back(t.e1);
+    }
+    c->spans.clear();
+}
+
+int get_twiddles(stx_ctx* c, int n, float2** out) {
+    auto it = c->twiddles.find(n);
+    if (it != c->twiddles.end()) { *out = it->second; return STX_OK; }
+    std::vector<float2> h((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    float2* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(float2) * (size_t)n));
+    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    c->twiddles[n] = d;
+    *out = d;
+    return STX_OK;
+}
+
+// numpy.round(x, 5) = rint(x * 1e5) / 1e5; the sample offsets of skimage's local_binary_pattern
+int lbp_offsets(int P, double R, LbpOffsets* o) {
+    if (P < 1 || P > 24) return -1;
+    for (int i = 0; i < P; ++i) {
+        const double ang = 2.0 * M_PI * (double)i / (double)P;
+        o->rp[i] = rint(-R * sin(ang) * 100000.0) / 100000.0;
+        o->cp[i] = rint(R * cos(ang) * 100000.0) / 100000.0;
+    }
+    return 0;
+}
+
+double dmin(double a, double b) { return a < b ? a : b; }
+
+// passive_checker.py:145-151
+double texture_score(const stx_metrics& m) {
+    return dmin(m.lbp_variance / 50.0, 1.0) * 0.3 + dmin(m.edge_density * 10, 1.0) * 0.2 +
+           (1.0 - dmin(m.compression_artifacts / 10.0, 1.0)) * 0.2 + dmin(m.noise_level / 20.0, 1.0) * 0.15 +
+           (1.0 - dmin(m.frequency_anomaly / 100.0, 1.0)) * 0.15;
+}
+
+// Population statistics (ddof = 0) from the device reductions: np.var :104, np.std :108/:123,
+// np.mean :113, count/size :117.
+void finalize(const FrameAcc& a, const Geom& g, int P, stx_metrics* m) {
+    memset(m, 0, sizeof(*m));
+    const uint64_t n = (uint64_t)g.H * (uint64_t)g.W;
+    const double dn = (double)n;
+    m->n_pixels = n;
+    for (int k = 0; k < STX_LBP_MAX_BINS; ++k) m->lbp_hist[k] = a.lbp_hist[k];
+    m->edge_count = a.edge_count;
+    m->absdiff_sum = a.absdiff_sum;
+    m->hp_sum = a.hp_sum;
+    m->hp_sumsq = a.hp_sumsq;
+    m->gray_sum = a.gray_sum;
+    m->fft_sum = a.fft_sum;
+    m->fft_sumsq = a.fft_sumsq;
+    double s1 = 0.0;
+    for (int k = 0; k < P + 2; ++k) s1 += (double)k * (double)a.lbp_hist[k];
+    const double mean = s1 / dn;
+    double acc = 0.0;
+    for (int k = 0; k < P + 2; ++k) acc += (double)a.lbp_hist[k] * ((double)k - mean) * ((double)k - mean);
+    m->lbp_variance = acc / dn;
+    const unsigned __int128 num =
+        (unsigned __int128)n * a.hp_sumsq - (unsigned __int128)a.hp_sum * (unsigned __int128)a.hp_sum;
+    m->noise_level = sqrt((double)num / (dn * dn));
+    m->compression_artifacts = (double)a.absdiff_sum / dn;
+    m->edge_density = (double)a.edge_count / dn;
+    const double nf = (double)g.fh * (double)g.fw;
+    const double fm = a.fft_sum / nf;
+    const double fv = a.fft_sumsq / nf - fm * fm;
+    m->frequency_anomaly = fv > 0.0 ? sqrt(fv) : 0.0;
+    m->texture_score = texture_score(*m);
+}
+
+int make_geom(stx_ctx* c, int h, int w, const stx_params& p, Geom* g) {
+    if (h < 1 || w < 1) return fail(c, STX_ERR_INVALID, "frame height and width must be >= 1");
+    if (h > STX_MAX_DIM || w > STX_MAX_DIM) return fail(c, STX_ERR_UNSUPPORTED, "frame larger than 8192 in one dimension");
+    g->H = h; g->W = w;
+    g->gpitch = ((w + 63) / 64) * 64 + 64;
+    g->grows = h + 4;
+    g->wpr = (w + 63) / 64;
+    g->tiles_x = g->wpr;
+    g->tiles_y = (h + 31) / 32;
+    g->htiles_y = (h + 63) / 64;
+    g->fh = p.fft_h > 0 ? p.fft_h : h;
+    g->fw = p.fft_w > 0 ? p.fft_w : w;
+    if (g->fh > h || g->fw > w) return fail(c, STX_ERR_INVALID, "fft crop larger than the frame");
+    g->foy = (h - g->fh) / 2;
+    g->fox = (w - g->fw) / 2;
+    g->fwh = g->fw / 2 + 1;
+    return STX_OK;
+}
+
+int check_params(stx_ctx* c, const stx_params& p) {
+    if (p.lbp_points < 1 || p.lbp_points > 24) return fail(c, STX_ERR_UNSUPPORTED, "lbp_points must be in 1..24");
+    if (!(p.lbp_radius > 0.0) || p.lbp_radius > 16.0) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius must be in (0,16]");
+    if (p.gray_shift != 14 && p.gray_shift != 15) return fail(c, STX_ERR_INVALID, "gray_shift must be 14 or 15");
+    if (p.canny_low < 0 || p.canny_high < 0) return fail(c, STX_ERR_INVALID, "canny thresholds must be >= 0");
+    if (p.fft_h < 0 || p.fft_w < 0) return fail(c, STX_ERR_INVALID, "fft crop must be >= 0");
+    return STX_OK;
+}
+
+size_t per_frame_workspace(const Geom& g) {
+    return (size_t)g.grows * g.gpitch + 2 * (size_t)g.H * g.wpr * 8 + (size_t)g.fh * g.fwh * sizeof(float2);
+}
+
+int pick_chunk(const stx_ctx* c, const Geom& g, int n_frames) {
+    int f;
+    if (c->chunk_override > 0) {
+        f = c->chunk_override;
+    } else {
+        // keep one chunk's intermediates inside the 256 MiB Infinity Cache
+        const size_t budget = (size_t)160 << 20;
+        f = (int)std::max<size_t>(1, budget / per_frame_workspace(g));
+        f = std::min(f, 4096);
+    }
+    return std::min(f, n_frames);
+}
+
+struct ChunkOpts {
+    uint8_t* codes = nullptr;  // device, optional [F][H][W]
+};
+
+// Runs the whole path for F frames resident on the device and leaves the reductions in
+// c->acc_host[0..F).
+int run_chunk(stx_ctx* c, const uint8_t* bgr_dev, int64_t row_stride, int64_t frame_stride, int F, const Geom& g,
+              const stx_params& p, const FftPlan& plan_w, const FftPlan& plan_h, const float2* tw_w, const float2* tw_h,
+              const LbpOffsets& off, const ChunkOpts& opts) {
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = ensure(c, c->gray, (size_t)F * g.grows * g.gpitch)) != STX_OK) return rc;
+    const size_t bm = (size_t)F * g.H * g.wpr * sizeof(unsigned long long);
+    if ((rc = ensure(c, c->strong, bm)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->cand, bm)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->spec, (size_t)F * g.fh * g.fwh * sizeof(float2))) != STX_OK) return rc;
+    const int cb = fft_cols_per_block(g.fh);
+    const int ncb = (g.fwh + cb - 1) / cb;
+    if ((rc = ensure(c, c->part, (size_t)F * ncb * sizeof(double2))) != STX_OK) return rc;
+    if ((rc = ensure(c, c->tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
+    if ((rc = ensure(c, c->acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
+    if ((rc = ensure(c, c->changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
+    if ((size_t)F > c->acc_host_cap) {
+        if (c->acc_host) HIPCHK(c, hipHostFree(c->acc_host));
+        c->acc_host = nullptr;
+        c->acc_host_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->acc_host, sizeof(FrameAcc) * (size_t)F * 2, hipHostMallocDefault));
+        c->acc_host_cap = (size_t)F * 2;
+    }
+    FrameAcc* acc = (FrameAcc*)c->acc.p;
+    unsigned int* changed = (unsigned int*)c->changed.p;
+    unsigned long long* strong = (unsigned long long*)c->strong.p;
+    unsigned long long* cand = (unsigned long long*)c->cand.p;
+    uint32_t* tiles = (uint32_t*)c->tiles.p;
+
+    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
+    HIPCHK(c, hipMemsetAsync(changed, 0, (size_t)HYST_MAX_PASSES * sizeof(unsigned int), s));
+
+    {
+        Span sp(c, STX_K_GRAY, 1);
+        launch_gray(s, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)c->gray.p, acc);
+        sp.end();
+    }
+    const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
+    {
+        Span sp(c, STX_K_STENCIL, 1);
+        launch_stencil(s, (const uint8_t*)c->gray.p, F, g, lbp81, off, p.canny_low, p.canny_high, acc, strong, cand,
+                       lbp81 ? opts.codes : nullptr);
+        sp.end();
+    }
+    if (!lbp81) {
+        Span sp(c, STX_K_LBP_GENERIC, 1);
+        launch_lbp_generic(s, (const uint8_t*)c->gray.p, F, g, p.lbp_points, off, 0, acc, opts.codes);
+        sp.end();
+    }
+    // first group of hysteresis passes; the FFT is queued behind it so the host's wait for the
+    // "changed" counter overlaps device work
+    int pass = 0;
+    auto hyst_group = [&]() -> int {
+        Span sp(c, STX_K_HYST, HYST_GROUP);
+        for (int i = 0; i < HYST_GROUP; ++i, ++pass) launch_hyst_pass(s, strong, cand, F, g, changed, pass, tiles);
+        sp.end();
+        HIPCHK(c, hipMemcpyAsync(c->changed_host, changed + (pass - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        return STX_OK;
+    };
+    if ((rc = hyst_group()) != STX_OK) return rc;
+    {
+        Span sp(c, STX_K_FFT_ROWS, 1);
+        launch_fft_rows(s, (const uint8_t*)c->gray.p, F, g, plan_w, tw_w, (float2*)c->spec.p);
+        sp.end();
+    }
+    int ncb2 = 0;
+    {
+        Span sp(c, STX_K_FFT_COLS, 1);
+        launch_fft_cols(s, (const float2*)c->spec.p, F, g, plan_h, tw_h, (double2*)c->part.p, &ncb2);
+        sp.end();
+    }
+    {
+        Span sp(c, STX_K_REDUCE, 1);
+        launch_fft_reduce(s, (const double2*)c->part.p, F, ncb2, acc);
+        sp.end();
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    while (*c->changed_host != 0) {
+        if (pass + HYST_GROUP > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
+        if ((rc = hyst_group()) != STX_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    {
+        Span sp(c, STX_K_REDUCE, 1);
+        launch_edge_count(s, tiles, F, g, acc);
+        sp.end();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->acc_host, acc, (size_t)F * sizeof(FrameAcc), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    if (c->timing) {
+        collect_spans(c);
+        c->tacc.frames += (uint64_t)F;
+    }
+    return STX_OK;
+}
+
+struct Prepared {
+    stx_params p;
+    Geom g;
+    FftPlan plan_w, plan_h;
+    float2 *tw_w, *tw_h;
+    LbpOffsets off;
+};
+
+int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
+    if (!c) return STX_ERR_INVALID;
+    if (params) pr->p = *params; else stx_default_params(&pr->p);
+    int rc;
+    if ((rc = check_params(c, pr->p)) != STX_OK) return rc;
+    if ((rc = make_geom(c, h, w, pr->p, &pr->g)) != STX_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!make_fft_plan(pr->g.fw, &pr->plan_w) || !make_fft_plan(pr->g.fh, &pr->plan_h))
+        return fail(c, STX_ERR_UNSUPPORTED, "FFT size has too many prime factors");
+    if ((rc = get_twiddles(c, pr->g.fw, &pr->tw_w)) != STX_OK) return rc;
+    if ((rc = get_twiddles(c, pr->g.fh, &pr->tw_h)) != STX_OK) return rc;
+    if (lbp_offsets(pr->p.lbp_points, pr->p.lbp_radius, &pr->off) != 0) return fail(c, STX_ERR_INVALID, "bad lbp_points");
+    return STX_OK;
+}
+
+int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_t row_stride, int64_t frame_stride,
+                        const Prepared& pr, stx_metrics* out) {
+    const int chunk = pick_chunk(c, pr.g, n_frames);
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int F = std::min(chunk, n_frames - f0);
+        ChunkOpts o;
+        int rc = run_chunk(c, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr.g, pr.p, pr.plan_w,
+                           pr.plan_h, pr.tw_w, pr.tw_h, pr.off, o);
+        if (rc != STX_OK) return rc;
+        for (int i = 0; i < F; ++i) finalize(c->acc_host[i], pr.g, pr.p.lbp_points, out + f0 + i);
+    }
+    return STX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* stx_version(void) { return "sift-texture-gfx950 0.1"; }
+
+void stx_default_params(stx_params* p) {
+    if (!p) return;
+    p->lbp_points = 8;
+    p->lbp_radius = 1.0;
+    p->canny_low = 50;
+    p->canny_high = 150;
+    p->gray_shift = 14;
+    p->fft_h = 0;
+    p->fft_w = 0;
+}
+
+int stx_create(int device_id, stx_ctx** out) {
+    if (!out) return STX_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return STX_ERR_HIP;
+    if (device_id < 0 || device_id >= ndev) return STX_ERR_INVALID;
+    stx_ctx* c = new (std::nothrow) stx_ctx();
+    if (!c) return STX_ERR_NOMEM;
+    c->device = device_id;
+    memset(&c->tacc, 0, sizeof(c->tacc));
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault) != hipSuccess ||
+        fft_set_lds_limits() != 0) {
+        if (c->stream) hipStreamDestroy(c->stream);
+        if (c->changed_host) hipHostFree(c->changed_host);
+        delete c;
+        return STX_ERR_HIP;
+    }
+    *c->changed_host = 0;
+    *out = c;
+    return STX_OK;
+}
+
+int stx_destroy(stx_ctx* c) {
+    if (!c) return STX_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->gray, &c->strong, &c->cand, &c->spec, &c->part, &c->tiles, &c->acc, &c->changed,
+                      &c->staging, &c->codes, &c->plane};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    for (auto& kv : c->twiddles) hipFree(kv.second);
+    if (c->acc_host) hipHostFree(c->acc_host);
+    if (c->changed_host) hipHostFree(c->changed_host);
+    for (auto& t : c->spans) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return STX_OK;
+}
+
+const char* stx_last_error(const stx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int stx_backend(const stx_ctx* c) { return c ? 1 : 0; }
+
+int stx_analyze_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                             int64_t frame_stride, const stx_params* params, stx_metrics* out) {
+    if (!c) return STX_ERR_INVALID;
+    if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
+    if (n_frames == 0) return STX_OK;
+    if (!bgr_dev || !out) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
+    Prepared pr;
+    int rc = prepare(c, h, w, params, &pr);
+    if (rc != STX_OK) return rc;
+    return analyze_device_impl(c, bgr_dev, n_frames, row_stride, frame_stride, pr, out);
+}
+
+static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* const* list, int n_frames, int h, int w,
+                               int64_t row_stride, int64_t frame_stride, const stx_params* params, stx_metrics* out) {
+    if (!c) return STX_ERR_INVALID;
+    if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
+    if (n_frames == 0) return STX_OK;
+    if ((!base && !list) || !out) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (row_stride < (int64_t)3 * w) return fail(c, STX_ERR_INVALID, "row stride smaller than 3*w");
+    Prepared pr;
+    int rc = prepare(c, h, w, params, &pr);
+    if (rc != STX_OK) return rc;
+    // device staging: rows padded to a multiple of 4 bytes so the gray kernel's dword path applies
+    const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
+    const int64_t dframe = dpitch * h;
+    const int chunk = pick_chunk(c, pr.g, n_frames);
+    if ((rc = ensure(c, c->staging, (size_t)chunk * dframe)) != STX_OK) return rc;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int F = std::min(chunk, n_frames - f0);
+        for (int i = 0; i < F; ++i) {
+            const uint8_t* src = list ? list[f0 + i] : base + (int64_t)(f0 + i) * frame_stride;
+            if (!src) return fail(c, STX_ERR_INVALID, "null frame pointer");
+            HIPCHK(c, hipMemcpy2DAsync((uint8_t*)c->staging.p + (int64_t)i * dframe, (size_t)dpitch, src, (size_t)row_stride,
+                                       (size_t)3 * w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        }
+        ChunkOpts o;
+        rc = run_chunk(c, (const uint8_t*)c->staging.p, dpitch, dframe, F, pr.g, pr.p, pr.plan_w, pr.plan_h, pr.tw_w,
+                       pr.tw_h, pr.off, o);
+        if (rc != STX_OK) return rc;
+        for (int i = 0; i < F; ++i) finalize(c->acc_host[i], pr.g, pr.p.lbp_points, out + f0 + i);
+    }
+    return STX_OK;
+}
+
+int stx_analyze_batch(stx_ctx* c, const uint8_t* bgr, int n_frames, int h, int w, int64_t row_stride,
+                      int64_t frame_stride, const stx_params* params, stx_metrics* out) {
+    if (c && n_frames > 1 && frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "frame stride smaller than the frame");
+    return analyze_host_common(c, bgr, nullptr, n_frames, h, w, row_stride, frame_stride, params, out);
+}
+
+int stx_analyze_frames(stx_ctx* c, const uint8_t* const* frames, int n_frames, int h, int w, int64_t row_stride,
+                       const stx_params* params, stx_metrics* out) {
+    return analyze_host_common(c, nullptr, frames, n_frames, h, w, row_stride, 0, params, out);
+}
+
+int stx_score_summary(const stx_metrics* m, int n, double threshold, double* average, int* passed) {
+    if (n < 0 || (n > 0 && !m) || !average || !passed) return STX_ERR_INVALID;
+    // numpy.mean: pairwise summation as numpy's add.reduce does it (eight running partial
+    // sums below 128 elements, halving above), so the average matches np.mean(scores) at
+    // passive_checker.py:155 bit for bit; 0.0 for an empty list
+    std::vector<double> v((size_t)n);
+    for (int i = 0; i < n; ++i) v[i] = m[i].texture_score;
+    struct PW {
+        static double sum(const double* a, int n) {
+            if (n < 8) {
+                double r = 0.0;
+                for (int i = 0; i < n; ++i) r += a[i];
+                return r;
+            }
+            if (n <= 128) {
+                double r[8];
+                for (int j = 0; j < 8; ++j) r[j] = a[j];
+                int i = 8;
+                for (; i < n - (n % 8); i += 8)
+                    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+                double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < n; ++i) res += a[i];
+                return res;
+            }
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            return sum(a, n2) + sum(a + n2, n - n2);
+        }
+    };
+    const double s = PW::sum(v.data(), n);
+    *average = n ? s / (double)n : 0.0;
+    *passed = (*average >= threshold) ? 1 : 0;
+    return STX_OK;
+}
+
+int stx_debug_planes(stx_ctx* c, const uint8_t* bgr, int h, int w, int64_t row_stride, const stx_params* params,
+                     uint8_t* gray_out, uint8_t* lbp_codes_out, uint8_t* edges_out) {
+    if (!c) return STX_ERR_INVALID;
+    if (!bgr) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (row_stride < (int64_t)3 * w) return fail(c, STX_ERR_INVALID, "row stride smaller than 3*w");
+    Prepared pr;
+    int rc = prepare(c, h, w, params, &pr);
+    if (rc != STX_OK) return rc;
+    const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
+    if ((rc = ensure(c, c->staging, (size_t)dpitch * h)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->codes, (size_t)h * w)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->plane, (size_t)h * w)) != STX_OK) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->staging.p, (size_t)dpitch, bgr, (size_t)row_stride, (size_t)3 * w, (size_t)h,
+                               hipMemcpyHostToDevice, c->stream));
+    ChunkOpts o;
+    o.codes = (uint8_t*)c->codes.p;
+    rc = run_chunk(c, (const uint8_t*)c->staging.p, dpitch, dpitch * h, 1, pr.g, pr.p, pr.plan_w, pr.plan_h, pr.tw_w,
+                   pr.tw_h, pr.off, o);
+    if (rc != STX_OK) return rc;
+    if (gray_out)
+        HIPCHK(c, hipMemcpy2DAsync(gray_out, (size_t)w, (const uint8_t*)c->gray.p + (size_t)GRAY_YOFF * pr.g.gpitch + GRAY_XOFF,
+                                   (size_t)pr.g.gpitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, c->stream));
+    if (lbp_codes_out)
+        HIPCHK(c, hipMemcpyAsync(lbp_codes_out, c->codes.p, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
+    if (edges_out) {
+        launch_edges_expand(c->stream, (const unsigned long long*)c->strong.p, pr.g, (uint8_t*)c->plane.p);
+        HIPCHK(c, hipMemcpyAsync(edges_out, c->plane.p, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return STX_OK;
+}
+
+int stx_synth_device(stx_ctx* c, uint8_t* bgr_dev, int kind, uint64_t seed, uint32_t video, uint32_t frame0, int n_frames,
+                     int h, int w) {
+    if (!c) return STX_ERR_INVALID;
+    if (!bgr_dev || n_frames < 0 || h < 1 || w < 1 || h > 8192 || w > 8192 || kind < 0 || kind > 5 ||
+        (uint64_t)frame0 + (uint64_t)n_frames > 1024 || video >= (1u << 28) || n_frames > 65535)
+        return fail(c, STX_ERR_INVALID, "synthetic generator limits: h,w<=8192, frame<1024, video<2^28");
+    if (n_frames == 0) return STX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Span sp(c, STX_K_SYNTH, 1);
+    launch_synth(c->stream, bgr_dev, kind, seed, video, frame0, n_frames, h, w);
+    sp.end();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (c->timing) collect_spans(c);
+    return STX_OK;
+}
+
+int stx_device_alloc(stx_ctx* c, uint64_t bytes, void** out) {
+    if (!c || !out) return STX_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(out, (size_t)bytes);
+    if (e != hipSuccess) return fail(c, STX_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return STX_OK;
+}
+int stx_device_free(stx_ctx* c, void* p) {
+    if (!c) return STX_ERR_INVALID;
+    HIPCHK(c, hipFree(p));
+    return STX_OK;
+}
+int stx_pinned_alloc(stx_ctx* c, uint64_t bytes, void** out) {
+    if (!c || !out) return STX_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, STX_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return STX_OK;
+}
+int stx_pinned_free(stx_ctx* c, void* p) {
+    if (!c) return STX_ERR_INVALID;
+    HIPCHK(c, hipHostFree(p));
+    return STX_OK;
+}
+int stx_memcpy_d2h(stx_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return STX_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return STX_OK;
+}
+int stx_memcpy_h2d(stx_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return STX_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return STX_OK;
+}
+
+int stx_set_chunk_frames(stx_ctx* c, int frames) {
+    if (!c || frames < 0) return STX_ERR_INVALID;
+    c->chunk_override = frames;
+    return STX_OK;
+}
+int stx_set_timing(stx_ctx* c, int enabled) {
+    if (!c) return STX_ERR_INVALID;
+    c->timing = enabled != 0;
+    return STX_OK;
+}
+int stx_get_timing(stx_ctx* c, stx_timing* out, int reset) {
+    if (!c || !out) return STX_ERR_INVALID;
+    *out = c->tacc;
+    if (reset) memset(&c->tacc, 0, sizeof(c->tacc));
+    return STX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Canny hysteresis (second half of cv2.Canny at /root/reference/app/passive_checker.py:116)
+// on one-bit-per-pixel maps: "strong" grows into every "candidate" pixel that is
+// 8-connected to it, transitively.
+//
+// One wave owns a 64x64 pixel tile: lane = row, one 64-bit word = that row's 64 pixels.
+// Vertical neighbours come from the adjacent lanes, horizontal ones from shifts, and a
+// strong bit floods a whole horizontal run of candidates in O(1) with a carry chain:
+// adding the seed bits to the run mask ripples a carry to the end of each run.  The tile
+// iterates to its local fix-point, then the host launches further passes until a pass
+// changes nothing anywhere (stale reads of a neighbouring tile's words are harmless: the
+// map only ever grows, and the last pass re-checks every tile against final neighbours).
+#include "stx_internal.h"
+
+namespace stx {
+
+__device__ __forceinline__ unsigned long long brev64(unsigned long long v) {
+    return ((unsigned long long)__brev((uint32_t)v) << 32) | (unsigned long long)__brev((uint32_t)(v >> 32));
+}
+
+// all bits of the candidate runs in c that contain a bit of x (x subset of c)
+__device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, unsigned long long x) {
+    const unsigned long long up = (c ^ (c + x)) & c;
+    const unsigned long long cr = brev64(c), xr = brev64(x);
+    const unsigned long long dn = brev64((cr ^ (cr + xr)) & cr);
+    return up | dn | x;
+}
+
+__global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
+                                                       const unsigned long long* __restrict__ cand, int H, int wpr,
+                                                       int htiles_y, unsigned int* changed, int pass,
+                                                       uint32_t* __restrict__ tile_count) {
+    if (pass > 0 && changed[pass - 1] == 0) return;
+    const int frame = blockIdx.z, ty = blockIdx.y, wx = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int y = ty * 64 + lane;
+    unsigned long long* sb = strong + (int64_t)frame * H * wpr;
+    const unsigned long long* cb = cand + (int64_t)frame * H * wpr;
+    const bool rowin = y < H;
+    const bool hasl = wx > 0, hasr = wx + 1 < wpr;
+    unsigned long long S = 0, C = 0, Lw = 0, Rw = 0;
+    if (rowin) {
+        const int64_t i = (int64_t)y * wpr + wx;
+        S = sb[i];
+        C = cb[i];
+        if (hasl) Lw = sb[i - 1];
+        if (hasr) Rw = sb[i + 1];
+    }
+    // halo rows above and below the tile (own word and its two neighbours)
+    unsigned long long To = 0, Tl = 0, Tr = 0, Bo = 0, Bl = 0, Br = 0;
+    const int yt = ty * 64 - 1, yb = ty * 64 + 64;
+    if (yt >= 0) {
+        const int64_t i = (int64_t)yt * wpr + wx;
+        To = sb[i];
+        if (hasl) Tl = sb[i - 1];
+        if (hasr) Tr = sb[i + 1];
+    }
+    if (yb < H) {
+        const int64_t i = (int64_t)yb * wpr + wx;
+        Bo = sb[i];
+        if (hasl) Bl = sb[i - 1];
+        if (hasr) Br = sb[i + 1];
+    }
+    unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
+    unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
+    if (lane == 0) { upL = Tl; upR = Tr; }
+    if (lane == 63) { dnL = Bl; dnR = Br; }
+    // pixels of the neighbouring word columns that touch this word's first / last pixel
+    const unsigned long long carry = ((upL | Lw | dnL) >> 63) | (((upR | Rw | dnR) & 1ull) << 63);
+
+    const unsigned long long orig = S;
+    bool any;
+    do {
+        unsigned long long up = __shfl_up(S, 1, 64), dn = __shfl_down(S, 1, 64);
+        if (lane == 0) up = To;
+        if (lane == 63) dn = Bo;
+        const unsigned long long A = S | up | dn;
+        const unsigned long long D = A | (A << 1) | (A >> 1) | carry;
+        const unsigned long long seeds = (S | (C & D)) & C;
+        const unsigned long long nS = S | flood_runs(C, seeds);
+        any = __any(nS != S);
+        S = nS;
+    } while (any);
+
+    const bool ch = S != orig;
+    if (ch) sb[(int64_t)y * wpr + wx] = S;
+    if (__any(ch) && lane == 0) atomicAdd(&changed[pass], 1u);
+    uint32_t cnt = __popcll(S);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) tile_count[((int64_t)frame * htiles_y + ty) * wpr + wx] = cnt;
+}
+
+__global__ __launch_bounds__(256) void edge_count_kernel(const uint32_t* __restrict__ tile_count, int tiles,
+                                                         FrameAcc* __restrict__ acc) {
+    __shared__ uint32_t part[4];
+    const int frame = blockIdx.x;
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < tiles; i += 256) s += tile_count[(int64_t)frame * tiles + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) acc[frame].edge_count = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long long* __restrict__ strong, int H, int W,
+                                                           int wpr, uint8_t* __restrict__ edges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    edges[i] = ((strong[(int64_t)y * wpr + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : 0;
+}
+
+void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count) {
+    dim3 grid(g.wpr, g.htiles_y, n_frames);
+    hipLaunchKernelGGL(hyst_pass_kernel, grid, dim3(64), 0, s, strong, cand, g.H, g.wpr, g.htiles_y, changed, pass,
+                       tile_count);
+}
+
+void launch_edge_count(hipStream_t s, const uint32_t* tile_count, int n_frames, const Geom& g, FrameAcc* acc) {
+    hipLaunchKernelGGL(edge_count_kernel, dim3(n_frames), dim3(256), 0, s, tile_count, g.htiles_y * g.wpr, acc);
+}
+
+void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges) {
+    const int64_t n = (int64_t)g.H * g.W;
+    hipLaunchKernelGGL(edges_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, strong, g.H, g.W, g.wpr,
+                       edges);
+}
+
+}  // namespace stx

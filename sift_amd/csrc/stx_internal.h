@@ -1,0 +1,89 @@
+// Internal declarations shared by the HIP translation units of libsift_texture.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sift_texture.h"
+
+namespace stx {
+
+// Per-frame accumulators filled on the device, copied to the host once per chunk.
+struct FrameAcc {
+    uint32_t lbp_hist[STX_LBP_MAX_BINS];
+    uint32_t edge_count;
+    uint32_t pad0;
+    unsigned long long absdiff_sum;
+    unsigned long long hp_sum;
+    unsigned long long hp_sumsq;
+    unsigned long long gray_sum;
+    double fft_sum;
+    double fft_sumsq;
+};
+
+// Geometry of one chunk of equally sized frames in the workspace.
+struct Geom {
+    int H, W;        // frame size
+    int gpitch;      // bytes per row of the padded gray plane: roundup(W,64)+64
+    int grows;       // rows of the padded gray plane: H+4 (two reflected rows above and below)
+    int wpr;         // 64-pixel bitmap words per row: ceil(W/64)
+    int tiles_x;     // ceil(W/64)
+    int tiles_y;     // ceil(H/32) stencil tiles
+    int htiles_y;    // ceil(H/64) hysteresis tiles
+    int fh, fw;      // FFT extent
+    int foy, fox;    // FFT crop origin in the frame
+    int fwh;         // fw/2+1 half-spectrum columns
+};
+
+// The padded gray plane stores pixel (y,x) at [(y+2)*gpitch + x+4]; rows -2..H+1 and
+// columns -2..W+1 hold BORDER_REFLECT_101 copies.
+constexpr int GRAY_XOFF = 4;
+constexpr int GRAY_YOFF = 2;
+
+struct LbpOffsets {
+    double rp[24];
+    double cp[24];
+};
+
+constexpr int FFT_MAX_PASSES = 16;
+struct FftPlan {
+    int n;
+    int npass;
+    int radix[FFT_MAX_PASSES];
+};
+
+// ---- launchers (each file owns its kernels) ----
+void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
+                 const Geom& g, int shift, uint8_t* gray, FrameAcc* acc);
+
+void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
+                    const LbpOffsets& off, int low, int high, FrameAcc* acc, unsigned long long* strong,
+                    unsigned long long* cand, uint8_t* codes_out);
+
+void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
+                        int halo, FrameAcc* acc, uint8_t* codes_out);
+
+// One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
+// changed nothing.  changed[] must be zeroed before pass 0.
+void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count);
+void launch_edge_count(hipStream_t s, const uint32_t* tile_count, int n_frames, const Geom& g, FrameAcc* acc);
+void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);
+
+// Real 2-D FFT of the (cropped) gray plane minus 128, log-magnitude statistics.
+// spec: [n_frames][fh][fwh] float2 intermediate.  part: [n_frames][col_blocks] double2.
+int fft_lds_bytes_rows(int n, int* nb_out);
+void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftPlan& plan,
+                     const float2* tw, float2* spec);
+int fft_cols_per_block(int n);
+void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftPlan& plan,
+                     const float2* tw, double2* part, int* col_blocks_out);
+void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int col_blocks, FrameAcc* acc);
+
+void launch_synth(hipStream_t s, uint8_t* bgr, int kind, uint64_t seed, uint32_t video, uint32_t frame0, int n_frames,
+                  int h, int w);
+
+bool make_fft_plan(int n, FftPlan* plan);
+int fft_set_lds_limits();
+
+}  // namespace stx

@@ -1,0 +1,339 @@
+// Fused stencil pass over the padded gray plane: one LDS tile feeds
+//   * uniform LBP (P=8, R=1) codes -> 10-bin histogram      (passive_checker.py:103-104)
+//   * 3x3 high-pass, saturated -> sum and sum of squares     (:107-108)
+//   * 5x5 Gaussian residual |gray - blur| -> sum             (:111-113)
+//   * Sobel + L1 magnitude + non-maximum suppression + double threshold
+//     -> two bitmaps (strong, candidate), one bit per pixel  (:116, first half of Canny)
+// A 256-thread workgroup owns a 64x32 pixel tile; each wave owns 8 rows, each lane one
+// column, and marches down its column with the 5x5 neighbourhood held in registers.  The
+// wave's 64 lanes are 64 consecutive pixels, so __ballot() of a per-pixel predicate IS the
+// 64-bit bitmap word of that row.
+//
+// LBP arithmetic is fp64 with every operation rounded separately in the order scikit-image
+// performs it; this file must be compiled with -ffp-contract=off.
+#include "stx_internal.h"
+
+namespace stx {
+
+#pragma clang fp contract(off)
+
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 32;
+constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+33
+constexpr int LPITCH = 72;         // bytes: columns x0-4 .. x0+67
+constexpr int LDW = LPITCH / 4;
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64s(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One bilinear sample exactly as skimage's bilinear_interpolation: top/bottom rows first,
+// then the vertical blend; returns the LBP bit (sample - centre >= 0).
+__device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, double bl, double br, double dr, double dc,
+                                            double centre) {
+    const double omc = 1.0 - dc;
+    const double omr = 1.0 - dr;
+    const double top = omc * tl + dc * tr;
+    const double bottom = omc * bl + dc * br;
+    const double t = omr * top + dr * bottom;
+    return (t - centre >= 0.0) ? 1u : 0u;
+}
+
+struct StencilArgs {
+    const uint8_t* gray;
+    int H, W, gpitch, grows, wpr;
+    int low, high;
+    double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
+    FrameAcc* acc;
+    unsigned long long* strong;
+    unsigned long long* cand;
+    uint8_t* codes;  // optional per-pixel LBP codes [frame][H][W]
+};
+
+template <bool BORDER, bool DO_LBP, bool CODES>
+__device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, int frame, int x0, int y0, int lane,
+                                      int wv, uint32_t* red /*[16] per wave*/) {
+    const int H = a.H, W = a.W;
+    const int x = x0 + lane;
+    const int ys = y0 + wv * 8;
+    const int lc = lane + GRAY_XOFF;  // LDS column of pixel x
+    const bool xin = x < W;
+
+    // LDS column indices for the Canny (replicated border) view
+    int cc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) cc[j] = BORDER ? (iclamp(x + j - 2, 0, W - 1) - x0 + GRAY_XOFF) : (lc + j - 2);
+
+    // per-column LBP weights
+    double dcP = 0, dcN = 0;
+    if (DO_LBP) {
+        const double cfp = (double)x + a.cp_pos;
+        dcP = cfp - floor(cfp);
+        const double cfn = (double)x + a.cp_neg;
+        dcN = cfn - floor(cfn);
+    }
+
+    // sliding state
+    int g[5][5];   // reflected view, rows y-2..y+2, cols x-2..x+2
+    int hg[5];     // horizontal [1 4 6 4 1] of those rows
+    int sd[3][3];  // horizontal Sobel difference of rows y, y+1, y+2 (Canny view) at x-1,x,x+1
+    int ss[3][3];  // horizontal Sobel smoothing of the same
+    int mag[3][3]; // L1 magnitude rows y-1..y+1, cols x-1..x+1 (0 outside the image)
+    int dxc[2], dyc[2];  // gradient at (y,x) and (y+1,x)
+
+    auto load_row = [&](int r, int (&gr)[5], int& hsum, int (&d)[3], int (&s)[3]) {
+        // r: global row index in [y0-2, y0+33]
+        const uint8_t* rowp = tile + (r - y0 + 2) * LPITCH;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) gr[j] = rowp[lc + j - 2];
+        hsum = gr[0] + gr[4] + 4 * (gr[1] + gr[3]) + 6 * gr[2];
+        int c5[5];
+        if (BORDER) {
+            const uint8_t* rowc = tile + (iclamp(r, 0, H - 1) - y0 + 2) * LPITCH;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) c5[j] = rowc[cc[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) c5[j] = gr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            d[j] = c5[j + 2] - c5[j];
+            s[j] = c5[j] + 2 * c5[j + 1] + c5[j + 2];
+        }
+    };
+    auto sobel_row = [&](int r, const int (&d0)[3], const int (&d1)[3], const int (&d2)[3], const int (&s0)[3],
+                         const int (&s2)[3], int (&m)[3], int& gx, int& gy) {
+        // gradient of row r from the three rows r-1, r, r+1
+        const bool rin = !BORDER || (r >= 0 && r < H);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ddx = d0[j] + 2 * d1[j] + d2[j];
+            const int ddy = s2[j] - s0[j];
+            int mm = abs(ddx) + abs(ddy);
+            if (BORDER) {
+                const int xx = x + j - 1;
+                if (!rin || xx < 0 || xx >= W) mm = 0;
+            }
+            m[j] = mm;
+            if (j == 1) { gx = ddx; gy = ddy; }
+        }
+    };
+
+    // prologue: rows ys-2 .. ys+1
+    int dtmp[3], stmp[3];
+    load_row(ys - 2, g[0], hg[0], dtmp, stmp);           // Sobel never needs row ys-2
+    int dm1[3], sm1[3];
+    load_row(ys - 1, g[1], hg[1], dm1, sm1);
+    load_row(ys, g[2], hg[2], sd[0], ss[0]);
+    load_row(ys + 1, g[3], hg[3], sd[1], ss[1]);
+    {
+        // magnitude row ys-1 needs row ys-2 in the Canny view
+        int gx, gy;
+        sobel_row(ys - 1, dtmp, dm1, sd[0], stmp, ss[0], mag[0], gx, gy);
+        sobel_row(ys, dm1, sd[0], sd[1], sm1, ss[1], mag[1], dxc[0], dyc[0]);
+    }
+
+    unsigned long long hist6 = 0;  // ten 6-bit counters
+    uint32_t hp_s = 0, hp_q = 0, ad_s = 0;
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = ys + i;
+        load_row(y + 2, g[4], hg[4], sd[2], ss[2]);
+        sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
+        const bool valid = xin && (y < H);
+        const int c = g[2][2];
+
+        // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
+        {
+            int s9 = 0;
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) s9 += g[r][1] + g[r][2] + g[r][3];
+            const int v = iclamp(9 * c - s9, 0, 255);
+            if (valid) { hp_s += v; hp_q += v * v; }
+        }
+        // ---- Gaussian residual
+        {
+            const int S = hg[0] + hg[4] + 4 * (hg[1] + hg[3]) + 6 * hg[2];
+            const int blur = (S + 128) >> 8;
+            if (valid) ad_s += abs(c - blur);
+        }
+        // ---- LBP (P=8, R=1)
+        if (DO_LBP) {
+            double n[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    int v = g[r + 1][q + 1];
+                    if (BORDER) {
+                        const int yy = y + r - 1, xx = x + q - 1;
+                        if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
+                    }
+                    n[r][q] = (double)v;
+                }
+            const double rfn = (double)y + a.rp_neg;  // samples above the centre
+            const double drN = rfn - floor(rfn);
+            const double rfp = (double)y + a.rp_pos;  // samples below
+            const double drP = rfp - floor(rfp);
+            const double ce = n[1][1];
+            uint32_t bits = 0;
+            bits |= (n[1][2] - ce >= 0.0) ? 1u : 0u;                                        // (0,+1)
+            bits |= lbp_bit(n[0][1], n[0][2], n[1][1], n[1][2], drN, dcP, ce) << 1;          // (-.7,+.7)
+            bits |= ((n[0][1] - ce >= 0.0) ? 1u : 0u) << 2;                                  // (-1,0)
+            bits |= lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce) << 3;          // (-.7,-.7)
+            bits |= ((n[1][0] - ce >= 0.0) ? 1u : 0u) << 4;                                  // (0,-1)
+            bits |= lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce) << 5;          // (+.7,-.7)
+            bits |= ((n[2][1] - ce >= 0.0) ? 1u : 0u) << 6;                                  // (+1,0)
+            bits |= lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce) << 7;          // (+.7,+.7)
+            const int changes = __popc((bits ^ (bits >> 1)) & 0x7Fu);
+            const int code = (changes <= 2) ? __popc(bits) : 9;
+            if (valid) {
+                hist6 += 1ull << (6 * code);
+                if (CODES) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)code;
+            }
+        }
+        // ---- Canny non-maximum suppression + double threshold
+        {
+            const int m = mag[1][1];
+            int cls = 0;
+            if (m > a.low) {
+                const int xs = dxc[0], ysg = dyc[0];
+                const int ax = abs(xs), ay = abs(ysg) << 15;
+                const int tg22x = ax * 13573;
+                bool keep;
+                if (ay < tg22x) {
+                    keep = (m > mag[1][0]) && (m >= mag[1][2]);
+                } else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) {
+                        keep = (m > mag[0][1]) && (m >= mag[2][1]);
+                    } else if ((xs ^ ysg) < 0) {
+                        keep = (m > mag[0][2]) && (m > mag[2][0]);
+                    } else {
+                        keep = (m > mag[0][0]) && (m > mag[2][2]);
+                    }
+                }
+                if (keep) cls = (m > a.high) ? 2 : 1;
+            }
+            if (!valid) cls = 0;
+            const unsigned long long sb = __ballot(cls == 2);
+            const unsigned long long cb = __ballot(cls >= 1);
+            if (lane == 0 && y < H) {
+                const int64_t wi = ((int64_t)frame * H + y) * a.wpr + (x0 >> 6);
+                a.strong[wi] = sb;
+                a.cand[wi] = cb;
+            }
+        }
+        // ---- slide down one row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) g[r][j] = g[r + 1][j];
+            hg[r] = hg[r + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                sd[r][j] = sd[r + 1][j];
+                ss[r][j] = ss[r + 1][j];
+                mag[r][j] = mag[r + 1][j];
+            }
+        dxc[0] = dxc[1];
+        dyc[0] = dyc[1];
+    }
+
+    // ---- wave reduction: 10 histogram bins (two words of five 12-bit fields), three sums
+    unsigned long long lo = 0, hi = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        lo |= ((hist6 >> (6 * b)) & 63ull) << (12 * b);
+        hi |= ((hist6 >> (6 * (b + 5))) & 63ull) << (12 * b);
+    }
+    lo = wave_sum_u64s(lo);
+    hi = wave_sum_u64s(hi);
+    hp_s = wave_sum_u32(hp_s);
+    hp_q = wave_sum_u32(hp_q);
+    ad_s = wave_sum_u32(ad_s);
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            red[b] = (uint32_t)((lo >> (12 * b)) & 0xFFFull);
+            red[b + 5] = (uint32_t)((hi >> (12 * b)) & 0xFFFull);
+        }
+        red[10] = hp_s;
+        red[11] = hp_q;
+        red[12] = ad_s;
+    }
+}
+
+template <bool DO_LBP, bool CODES>
+__global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
+    __shared__ uint32_t tile[LROWS * LDW];
+    __shared__ uint32_t red[4][16];
+    const int frame = blockIdx.z;
+    const int x0 = blockIdx.x * TILE_W;
+    const int y0 = blockIdx.y * TILE_H;
+    const int tid = threadIdx.x;
+
+    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
+    for (int i = tid; i < LROWS * LDW; i += 256) {
+        const int row = i / LDW;
+        const int col = i - row * LDW;
+        int gy = y0 + row;  // padded-plane row of global row y0-2+row
+        gy = gy < a.grows ? gy : a.grows - 1;
+        tile[i] = *reinterpret_cast<const uint32_t*>(gp + (int64_t)gy * a.gpitch + x0 + col * 4);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    // interior: the tile and its two-pixel halo lie inside the image
+    const bool interior = (x0 >= 2) && (y0 >= 2) && (x0 + TILE_W + 2 <= a.W) && (y0 + TILE_H + 2 <= a.H);
+    if (interior)
+        march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+    else
+        march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+    __syncthreads();
+    if (tid < 13) {
+        const uint32_t v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        FrameAcc* fa = a.acc + frame;
+        if (tid < 10) {
+            if (DO_LBP && v) atomicAdd(&fa->lbp_hist[tid], v);
+        } else if (v) {
+            unsigned long long* dst = tid == 10 ? &fa->hp_sum : (tid == 11 ? &fa->hp_sumsq : &fa->absdiff_sum);
+            atomicAdd(dst, (unsigned long long)v);
+        }
+    }
+}
+
+void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
+                    const LbpOffsets& off, int low, int high, FrameAcc* acc, unsigned long long* strong,
+                    unsigned long long* cand, uint8_t* codes_out) {
+    StencilArgs a;
+    a.gray = gray;
+    a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.wpr = g.wpr;
+    a.low = low; a.high = high;
+    // (P=8,R=1): samples 1,3 sit above the centre (rp<0), 5,7 below; 1,7 right (cp>0), 3,5 left
+    a.rp_neg = off.rp[1]; a.rp_pos = off.rp[5]; a.cp_pos = off.cp[1]; a.cp_neg = off.cp[3];
+    a.acc = acc; a.strong = strong; a.cand = cand; a.codes = codes_out;
+    dim3 grid(g.tiles_x, g.tiles_y, n_frames);
+    if (!do_lbp81)
+        hipLaunchKernelGGL((stencil_kernel<false, false>), grid, dim3(256), 0, s, a);
+    else if (codes_out)
+        hipLaunchKernelGGL((stencil_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((stencil_kernel<true, false>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace stx

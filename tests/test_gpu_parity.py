@@ -1,0 +1,221 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle.
+
+Integer quantities (gray plane, LBP codes and histogram, Canny edge map and count, high-pass
+sum / sum of squares, |gray-blur| sum) must be bit-exact; float metrics and scores must agree
+within 1e-4 relative (the FFT runs in fp32 on the device, fp64 in numpy).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cases import LBP_IMAGES, SCORE_SETS, SEED
+from oracle import texture_oracle as O
+from sift_amd.synth import KIND_ID, KINDS, synth_clip, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sift_amd.texture import TextureContext
+    c = TextureContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def det():
+    from sift_amd.texture import TextureNoiseDetector
+    return TextureNoiseDetector(0)
+
+
+def _check_record(r, m, P=8, rel=REL):
+    assert list(r.lbp_hist[:P + 2]) == list(m.lbp_hist[:P + 2])
+    assert r.edge_count == m.edge_count
+    assert r.absdiff_sum == m.absdiff_sum
+    assert r.hp_sum == m.hp_sum and r.hp_sumsq == m.hp_sumsq
+    assert r.gray_sum == m.gray_sum and r.n_pixels == m.n_pixels
+    for k in O.METRIC_KEYS:
+        a, b = getattr(r, k), getattr(m, k)
+        assert a == pytest.approx(b, rel=rel, abs=1e-9), k
+    assert r.texture_score == pytest.approx(m.texture_score, rel=rel, abs=1e-9)
+
+
+SIZES = [(1, 1), (1, 7), (5, 1), (2, 2), (3, 3), (5, 7), (24, 31), (33, 65), (64, 64), (45, 77), (80, 80),
+         (100, 130), (128, 192), (67, 200)]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_planes_bit_exact(ctx, coracle, kind):
+    for (h, w) in SIZES:
+        f = synth_frame(kind, SEED, 3, 1, h, w)
+        gray, codes, edges = ctx.debug_planes(f)
+        g = coracle.gray(f)
+        assert np.array_equal(gray, g), ("gray", kind, h, w)
+        want_codes, _ = coracle.lbp(g, 8, 1.0)
+        assert np.array_equal(codes, want_codes), ("lbp", kind, h, w, int((codes != want_codes).sum()))
+        want_edges, _, _ = coracle.canny(g)
+        assert np.array_equal(edges, want_edges), ("canny", kind, h, w, int((edges != want_edges).sum()))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_metrics_vs_oracle(ctx, coracle, kind):
+    for (h, w) in SIZES:
+        f = synth_frame(kind, SEED, 4, 2, h, w)
+        r = ctx.analyze_frames([f])[0]
+        m = coracle.analyze_frame(f)
+        # structured, noise-free images (ramp/flat/step) have most FFT bins at exactly zero in
+        # exact arithmetic; the fp32 noise floor shows in ln(|F|+1) there, so the spectral
+        # statistic is only held to 2e-3 for them
+        rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+        _check_record(r, m, rel=rel)
+
+
+def test_lbp_codes_vs_skimage_golden(ctx):
+    gold = np.load(os.path.join(GOLD, "lbp_skimage.npz"))
+    p16 = ctx.default_params(); p16.lbp_points = 16; p16.lbp_radius = 2.0
+    p24 = ctx.default_params(); p24.lbp_points = 24; p24.lbp_radius = 3.0
+    for idx, (kind, h, w) in enumerate(LBP_IMAGES):
+        g = synth_frame(kind, SEED, 0, idx, h, w)[..., 1]
+        bgr = np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))  # gray(v,v,v) == v
+        for P, prm in ((8, None), (16, p16), (24, p24)):
+            gray, codes, _ = ctx.debug_planes(bgr, prm)
+            assert np.array_equal(gray, g)
+            want = gold["lbp_%02d_%s_%dx%d_P%d" % (idx, kind, h, w, P)]
+            assert np.array_equal(codes, want), (kind, h, w, P, int((codes != want).sum()))
+
+
+def test_score_sets_golden(det):
+    gold = json.load(open(os.path.join(GOLD, "score_sets.json")))
+    for si, (name, kind, n, h, w) in enumerate(SCORE_SETS):
+        entry = gold[name]
+        frames = list(synth_clip(kind, SEED, 10 + si, n, h, w)) if n else []
+        res = det.compute_texture_score(frames)
+        want = entry["result"]
+        assert list(res.keys()) == ["passed", "average_score", "individual_scores", "detailed_metrics", "message"]
+        assert res["passed"] is want["passed"]
+        assert res["average_score"] == pytest.approx(want["average_score"], abs=1.001e-3)
+        assert len(res["individual_scores"]) == min(n, 10)
+        for a, b in zip(res["individual_scores"], want["individual_scores"]):
+            assert a == pytest.approx(b, abs=1.001e-3)
+        rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+        for d, wd in zip(res["detailed_metrics"], want["detailed_metrics"]):
+            assert list(d.keys()) == list(O.METRIC_KEYS)
+            for k in O.METRIC_KEYS:
+                assert isinstance(d[k], float)
+                assert d[k] == pytest.approx(wd[k], rel=rel, abs=1e-9), (name, k)
+        recs = det.analyze_frames_raw(frames[:10])
+        for r, ints in zip(recs, entry["integers"]):
+            assert list(r.lbp_hist[:10]) == ints["lbp_hist"]
+            assert (r.hp_sum, r.hp_sumsq, r.absdiff_sum, r.edge_count, r.gray_sum) == (
+                ints["hp_sum"], ints["hp_sumsq"], ints["absdiff_sum"], ints["edge_count"], ints["gray_sum"])
+        json.dumps(res)  # JSON-native leaves
+
+
+def test_batch_chunking_and_strides(ctx, coracle):
+    clip = synth_clip("natural", SEED, 21, 7, 72, 136)
+    want = [coracle.analyze_frame(f) for f in clip]
+    for chunk in (0, 1, 3):
+        ctx.set_chunk_frames(chunk)
+        res = ctx.analyze_batch(clip)
+        for r, m in zip(res, want):
+            _check_record(r, m)
+    ctx.set_chunk_frames(0)
+    # non-contiguous views: every second column of a wider clip, and a row-padded buffer
+    wide = synth_clip("noise", SEED, 22, 2, 40, 90)
+    views = [wide[i][:, ::2, :] for i in range(2)]
+    res = ctx.analyze_frames(views)
+    for r, v in zip(res, views):
+        _check_record(r, coracle.analyze_frame(np.ascontiguousarray(v)))
+    padded = np.zeros((40, 400), np.uint8)
+    fr = synth_frame("natural", SEED, 23, 0, 40, 121)
+    padded[:, :363] = fr.reshape(40, 363)
+    view = np.lib.stride_tricks.as_strided(padded, shape=(40, 121, 3), strides=(400, 3, 1))
+    _check_record(ctx.analyze_frames([view])[0], coracle.analyze_frame(fr))
+
+
+def test_device_resident_and_synth(ctx, coracle):
+    h, w, n = 96, 160, 5
+    nbytes = n * h * w * 3
+    dev = ctx.device_alloc(nbytes)
+    try:
+        for kind in KINDS:
+            ctx.synth_device(dev, KIND_ID[kind], SEED + 2, 5, 3, n, h, w)
+            got = ctx.d2h(dev, nbytes).reshape(n, h, w, 3)
+            want = synth_clip(kind, SEED + 2, 5, n, h, w, frame0=3)
+            assert np.array_equal(got, want), kind
+            res = ctx.analyze_device(dev, n, h, w)
+            for i in range(n):
+                rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+                _check_record(res[i], coracle.analyze_frame(want[i]), rel=rel)
+    finally:
+        ctx.device_free(dev)
+
+
+def test_params_fft_crop_gray15_thresholds(ctx, coracle):
+    f = synth_frame("natural", SEED, 30, 0, 120, 168)
+    p = ctx.default_params()
+    p.fft_h, p.fft_w = 64, 96
+    p.gray_shift = 15
+    p.canny_low, p.canny_high = 20, 60
+    p.lbp_points, p.lbp_radius = 16, 2.0
+    op = coracle.default_params()
+    op.fft_h, op.fft_w, op.gray_shift, op.canny_low, op.canny_high = 64, 96, 15, 20, 60
+    op.lbp_points, op.lbp_radius = 16, 2.0
+    r = ctx.analyze_frames([f], p)[0]
+    _check_record(r, coracle.analyze_frame(f, op), P=16)
+
+
+def test_odd_fft_sizes(ctx, coracle):
+    # prime and mixed sizes exercise the generic butterfly: 17x23, 7*11=77, 2*3*5*7=210, 13
+    for (h, w) in [(17, 23), (77, 13), (210, 66), (49, 121), (26, 34)]:
+        f = synth_frame("noise", SEED, 31, 0, h, w)
+        _check_record(ctx.analyze_frames([f])[0], coracle.analyze_frame(f))
+
+
+def test_long_contours_hysteresis(ctx, coracle):
+    # weak contours hundreds of pixels long hanging off a single strong seed: many
+    # tile-to-tile propagation passes
+    h, w = 200, 330
+    g = np.full((h, w), 40, np.uint8)
+    for y in range(4, h - 4, 6):  # serpentine of faint lines (gradient 4*12=48 < 50 alone...)
+        g[y, 4:w - 4] = 58
+    g[4:h - 4, 4] = 58
+    g[4:h - 4, w - 5] = 58
+    g[10:14, 10:14] = 255  # one strong blob touching the serpentine
+    bgr = np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))
+    gray, _, edges = ctx.debug_planes(bgr)
+    assert np.array_equal(gray, g)
+    want, nms, cnt = coracle.canny(g)
+    assert np.array_equal(edges, want)
+    assert ctx.analyze_frames([bgr])[0].edge_count == cnt
+
+
+def test_errors_are_python_exceptions(ctx, det):
+    from sift_amd._lib import StxError
+    with pytest.raises(ValueError):
+        det.analyze_frame(np.zeros((8, 8), np.uint8))
+    with pytest.raises(TypeError):
+        det.analyze_frame(np.zeros((8, 8, 3), np.float32))
+    p = ctx.default_params(); p.lbp_points = 40
+    with pytest.raises(StxError):
+        ctx.analyze_frames([np.zeros((8, 8, 3), np.uint8)], p)
+    p = ctx.default_params(); p.fft_h = 100
+    with pytest.raises(StxError):
+        ctx.analyze_frames([np.zeros((8, 8, 3), np.uint8)], p)
+    assert det.compute_texture_score([]) == {
+        "passed": False, "average_score": 0.0, "individual_scores": [], "detailed_metrics": [],
+        "message": "Texture analysis failed (score: 0.000)"}
+
+
+def test_two_detectors_one_process():
+    from sift_amd.texture import TextureNoiseDetector
+    a, b = TextureNoiseDetector(), TextureNoiseDetector()
+    f = synth_frame("natural", SEED, 40, 0, 64, 64)
+    assert a.analyze_frame(f) == b.analyze_frame(f)
+    assert a.threshold == 0.6
