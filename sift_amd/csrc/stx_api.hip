@@ -103,11 +103,11 @@ struct Span {
         t.e0 = get_event(c);
         t.e1 = get_event(c);
         if (!t.e0 || !t.e1) { on = false; return; }
-        hipEventRecord(t.e0, c->stream);
+        (void)hipEventRecord(t.e0, c->stream);
     }
     void end() {
         if (!on) return;
-        hipEventRecord(t.e1, c->stream);
+        (void)hipEventRecord(t.e1, c->stream);
         c->spans.push_back(t);
     }
 };
@@ -396,21 +396,37 @@ void stx_default_params(stx_params* p) {
     p->fft_w = 0;
 }
 
+static thread_local std::string g_create_err = "null context";
+
 int stx_create(int device_id, stx_ctx** out) {
     if (!out) return STX_ERR_INVALID;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return STX_ERR_HIP;
-    if (device_id < 0 || device_id >= ndev) return STX_ERR_INVALID;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        g_create_err = std::string("hipGetDeviceCount: ") + (e != hipSuccess ? hipGetErrorString(e) : "no devices");
+        return STX_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_err = "device id out of range";
+        return STX_ERR_INVALID;
+    }
     stx_ctx* c = new (std::nothrow) stx_ctx();
     if (!c) return STX_ERR_NOMEM;
     c->device = device_id;
     memset(&c->tacc, 0, sizeof(c->tacc));
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&c->changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault) != hipSuccess ||
-        fft_set_lds_limits() != 0) {
-        if (c->stream) hipStreamDestroy(c->stream);
-        if (c->changed_host) hipHostFree(c->changed_host);
+    const char* step = "hipSetDevice";
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
+    if (e == hipSuccess) {
+        step = "hipHostMalloc";
+        e = hipHostMalloc((void**)&c->changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
+    }
+    if (e == hipSuccess) { step = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; e = fft_set_lds_limits(); }
+    if (e != hipSuccess) {
+        g_create_err = std::string(step) + ": " + hipGetErrorString(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->changed_host) (void)hipHostFree(c->changed_host);
         delete c;
         return STX_ERR_HIP;
     }
@@ -421,23 +437,23 @@ int stx_create(int device_id, stx_ctx** out) {
 
 int stx_destroy(stx_ctx* c) {
     if (!c) return STX_ERR_INVALID;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->strong, &c->cand, &c->spec, &c->part, &c->tiles, &c->acc, &c->changed,
                       &c->staging, &c->codes, &c->plane};
     for (DevBuf* b : bufs)
-        if (b->p) hipFree(b->p);
-    for (auto& kv : c->twiddles) hipFree(kv.second);
-    if (c->acc_host) hipHostFree(c->acc_host);
-    if (c->changed_host) hipHostFree(c->changed_host);
-    for (auto& t : c->spans) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
-    for (auto e : c->event_pool) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (b->p) (void)hipFree(b->p);
+    for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    if (c->acc_host) (void)hipHostFree(c->acc_host);
+    if (c->changed_host) (void)hipHostFree(c->changed_host);
+    for (auto& t : c->spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return STX_OK;
 }
 
-const char* stx_last_error(const stx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* stx_last_error(const stx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 int stx_backend(const stx_ctx* c) { return c ? 1 : 0; }
 

@@ -192,18 +192,19 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     for (int c = 0; c < cb; ++c) {
         const int k = k0 + c;
         if (k >= a.fwh) break;
-        const float wgt = (k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.f : 2.f;
-        float ls = 0.f, ls2 = 0.f;
+        const double wgt = (k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0;
+        // accumulate in fp64: the variance is a difference of two nearly equal sums
+        double ls = 0.0, ls2 = 0.0;
         for (int y = tid; y < n; y += 256) {
             float2 v = f[c * n + y];
             if (k == 0 && y == 0) v.x += dc_fix;
             const float mag = sqrtf(v.x * v.x + v.y * v.y);
-            const float l = logf(mag + 1.0f);
+            const double l = (double)logf(mag + 1.0f);
             ls += l;
             ls2 += l * l;
         }
-        s += (double)(wgt * ls);
-        s2 += (double)(wgt * ls2);
+        s += wgt * ls;
+        s2 += wgt * ls2;
     }
     // deterministic block reduction: fixed shuffle tree, then waves in order
 #pragma unroll
@@ -259,7 +260,7 @@ bool make_fft_plan(int n, FftPlan* plan) {
 }
 
 constexpr int FFT_LDS_BUDGET = 64 * 1024;
-constexpr int FFT_LDS_MAX = 160 * 1024;
+constexpr int FFT_LDS_MAX = 159 * 1024;  // dynamic part; 1 KiB of the CU's 160 KiB is left for static LDS
 
 // LDS bytes for the row kernel and the number of row pairs per workgroup
 int fft_lds_bytes_rows(int n, int* nb_out) {
@@ -271,7 +272,7 @@ int fft_lds_bytes_rows(int n, int* nb_out) {
 }
 
 int fft_cols_per_block(int n) {
-    int cb = (FFT_LDS_MAX - 1024) / (2 * n * (int)sizeof(float2));  // 1 KiB left for static LDS
+    int cb = FFT_LDS_MAX / (2 * n * (int)sizeof(float2));
     if (cb > 8) cb = 8;
     if (cb < 1) cb = 1;
     return cb;
@@ -306,12 +307,12 @@ void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int col
     hipLaunchKernelGGL(fft_reduce_kernel, dim3(n_frames), dim3(64), 0, s, part, col_blocks, acc);
 }
 
-int fft_set_lds_limits() {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+hipError_t fft_set_lds_limits() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
 }
 
 }  // namespace stx

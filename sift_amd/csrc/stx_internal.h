@@ -84,6 +84,6 @@ void launch_synth(hipStream_t s, uint8_t* bgr, int kind, uint64_t seed, uint32_t
                   int h, int w);
 
 bool make_fft_plan(int n, FftPlan* plan);
-int fft_set_lds_limits();
+hipError_t fft_set_lds_limits();
 
 }  // namespace stx

@@ -27,7 +27,9 @@ class TextureContext:
         h = C.c_void_p()
         rc = self.lib.stx_create(int(device), C.byref(h))
         if rc != _lib.STX_OK or not h:
-            raise StxError(f"stx_create(device={device}) failed with code {rc}: no usable MI355X / HIP runtime")
+            why = self.lib.stx_last_error(None)
+            raise StxError(f"stx_create(device={device}) failed with code {rc} "
+                           f"({why.decode() if why else 'unknown'}): no usable MI355X / HIP runtime")
         self.handle = h
         self.device = int(device)
 
