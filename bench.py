@@ -72,6 +72,7 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sift_amd._lib import StxMetrics
+    from sift_amd.sharding import gather_rows
     from sift_amd.synth import KIND_ID
     from sift_amd.texture import METRIC_KEYS, TextureContext
 
@@ -108,9 +109,8 @@ def main() -> None:
     for i in range(args.steps):
         step(i, keep=i)
     if world > 1:
-        mine = torch.from_numpy(rows.reshape(-1)).cuda()
-        gathered = torch.empty(world * mine.numel(), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(gathered, mine)
+        # the one collective of the job: every rank's clips (video id = step*world + rank) in video order
+        all_rows = gather_rows(rows, args.steps * world, nf, device="cuda")
     sync()
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
@@ -119,9 +119,8 @@ def main() -> None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        all_rows = gathered.cpu().numpy().reshape(world, args.steps, nf, 6)
     else:
-        all_rows = rows[None]
+        all_rows = rows
 
     if rank == 0:
         frames_total = world * args.steps * nf
