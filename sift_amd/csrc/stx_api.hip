@@ -223,7 +223,7 @@ int check_params(stx_ctx* c, const stx_params& p) {
 }
 
 size_t per_frame_workspace(const Geom& g) {
-    return (size_t)g.grows * g.gpitch + 2 * (size_t)g.H * g.wpr * 8 + (size_t)g.fh * g.fwh * sizeof(float2);
+    return (size_t)g.grows * g.gpitch + 2 * (size_t)g.H * g.wpr * 8 + (size_t)g.fh * (g.fwh + 15) * sizeof(float2);
 }
 
 int pick_chunk(const stx_ctx* c, const Geom& g, int n_frames) {
@@ -254,10 +254,9 @@ int run_chunk(stx_ctx* c, const uint8_t* bgr_dev, int64_t row_stride, int64_t fr
     const size_t bm = (size_t)F * g.H * g.wpr * sizeof(unsigned long long);
     if ((rc = ensure(c, c->strong, bm)) != STX_OK) return rc;
     if ((rc = ensure(c, c->cand, bm)) != STX_OK) return rc;
-    if ((rc = ensure(c, c->spec, (size_t)F * g.fh * g.fwh * sizeof(float2))) != STX_OK) return rc;
-    const int cb = fft_cols_per_block(g.fh);
-    const int ncb = (g.fwh + cb - 1) / cb;
-    if ((rc = ensure(c, c->part, (size_t)F * ncb * sizeof(double2))) != STX_OK) return rc;
+    const FftLayout lay = fft_choose_layout(g);
+    if ((rc = ensure(c, c->spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
+    if ((rc = ensure(c, c->part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
     if ((rc = ensure(c, c->tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
     if ((rc = ensure(c, c->acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
     if ((rc = ensure(c, c->changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
@@ -307,18 +306,17 @@ int run_chunk(stx_ctx* c, const uint8_t* bgr_dev, int64_t row_stride, int64_t fr
     if ((rc = hyst_group()) != STX_OK) return rc;
     {
         Span sp(c, STX_K_FFT_ROWS, 1);
-        launch_fft_rows(s, (const uint8_t*)c->gray.p, F, g, plan_w, tw_w, (float2*)c->spec.p);
+        launch_fft_rows(s, (const uint8_t*)c->gray.p, F, g, lay, plan_w, tw_w, (float2*)c->spec.p);
         sp.end();
     }
-    int ncb2 = 0;
     {
         Span sp(c, STX_K_FFT_COLS, 1);
-        launch_fft_cols(s, (const float2*)c->spec.p, F, g, plan_h, tw_h, (double2*)c->part.p, &ncb2);
+        launch_fft_cols(s, (const float2*)c->spec.p, F, g, lay, plan_h, tw_h, (double2*)c->part.p);
         sp.end();
     }
     {
         Span sp(c, STX_K_REDUCE, 1);
-        launch_fft_reduce(s, (const double2*)c->part.p, F, ncb2, acc);
+        launch_fft_reduce(s, (const double2*)c->part.p, F, lay.parts_per_frame, acc);
         sp.end();
     }
     HIPCHK(c, hipStreamSynchronize(s));

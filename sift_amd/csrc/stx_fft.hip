@@ -121,6 +121,7 @@ struct FftRowsArgs {
     const uint8_t* gray;
     int gpitch, grows;
     int foy, fox, fh, fw, fwh;
+    int cbw, nkb;  // spectrum layout [frame][nkb][fh][cbw]
     int nb;  // complex transforms (row pairs) per workgroup
     FftPlan plan;
     const float2* tw;
@@ -150,13 +151,14 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(FftRowsArgs a) {
     for (int b = 0; b < nb; ++b) {
         const int ra = row0 + 2 * b, rb = ra + 1;
         if (ra >= a.fh) break;
-        float2* oa = a.spec + ((int64_t)frame * a.fh + ra) * a.fwh;
-        float2* ob = oa + a.fwh;
+        float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * a.cbw;
         for (int k = tid; k < a.fwh; k += 256) {
             const float2 zk = z[b * n + k];
             const float2 zc = z[b * n + (k ? n - k : 0)];
-            oa[k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-            if (rb < a.fh) ob[k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+            const int kb = k / a.cbw, kc = k - kb * a.cbw;
+            float2* o = base + ((int64_t)kb * a.fh + ra) * a.cbw + kc;
+            o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+            if (rb < a.fh) o[a.cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
         }
     }
 }
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     float2* buf1 = lds + cb * n;
     const int frame = blockIdx.y;
     const int k0 = blockIdx.x * cb;
-    const float2* sp = a.spec + (int64_t)frame * a.fh * a.fwh;
+    // one column block [n][cb] is contiguous
+    const float2* sp = a.spec + ((int64_t)frame * a.nblocks + blockIdx.x) * (int64_t)n * cb;
     for (int i = tid; i < cb * n; i += 256) {
         const int y = i / cb, c = i - y * cb;
         const int k = k0 + c;
-        buf0[c * n + y] = k < a.fwh ? sp[(int64_t)y * a.fwh + k] : make_float2(0.f, 0.f);
+        buf0[c * n + y] = k < a.fwh ? sp[i] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     const float2* f = fft_run(buf0, buf1, a.plan, cb, a.tw, tid, 256);
@@ -262,8 +265,8 @@ bool make_fft_plan(int n, FftPlan* plan) {
 constexpr int FFT_LDS_BUDGET = 64 * 1024;
 constexpr int FFT_LDS_MAX = 159 * 1024;  // dynamic part; 1 KiB of the CU's 160 KiB is left for static LDS
 
-// LDS bytes for the row kernel and the number of row pairs per workgroup
-int fft_lds_bytes_rows(int n, int* nb_out) {
+// LDS bytes for the generic row kernel and the number of row pairs per workgroup
+static int fft_lds_bytes_rows(int n, int* nb_out) {
     int nb = FFT_LDS_BUDGET / (2 * n * (int)sizeof(float2));
     if (nb < 1) nb = 1;
     if (nb > 8) nb = 8;
@@ -271,18 +274,37 @@ int fft_lds_bytes_rows(int n, int* nb_out) {
     return 2 * nb * n * (int)sizeof(float2);
 }
 
-int fft_cols_per_block(int n) {
-    int cb = FFT_LDS_MAX / (2 * n * (int)sizeof(float2));
-    if (cb > 8) cb = 8;
-    if (cb < 1) cb = 1;
-    return cb;
+// Spectrum layout [frame][nkb][fh][cbw]: blocks of cbw adjacent columns, each block contiguous,
+// so the column pass streams its input.  cbw is set by what the column kernel can hold in LDS.
+FftLayout fft_choose_layout(const Geom& g) {
+    FftLayout l;
+    l.fast_rows = fft_fast_available(g.fw);
+    l.fast_cols = fft_fast_available(g.fh);
+    int cbw;
+    if (l.fast_cols) {
+        const int stride = fft_fast_stride(g.fh);
+        cbw = 16;
+        while (cbw > 1 && (size_t)cbw * stride * sizeof(float2) > (size_t)FFT_LDS_MAX) cbw >>= 1;
+        const int tpw = fft_fast_tpw(g.fh);
+        if (cbw < tpw) cbw = tpw;
+    } else {
+        cbw = FFT_LDS_MAX / (2 * g.fh * (int)sizeof(float2));
+        if (cbw > 8) cbw = 8;
+        if (cbw < 1) cbw = 1;
+    }
+    l.cbw = cbw;
+    l.nkb = (g.fwh + cbw - 1) / cbw;
+    l.parts_per_frame = l.fast_cols ? l.nkb * cbw : l.nkb;
+    return l;
 }
 
-void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftPlan& plan,
-                     const float2* tw, float2* spec) {
+void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
+                     const FftPlan& plan, const float2* tw, float2* spec) {
+    if (lay.fast_rows && launch_fft_rows_fast(s, gray, n_frames, g, lay, tw, spec)) return;
     FftRowsArgs a;
     a.gray = gray; a.gpitch = g.gpitch; a.grows = g.grows;
     a.foy = g.foy; a.fox = g.fox; a.fh = g.fh; a.fw = g.fw; a.fwh = g.fwh;
+    a.cbw = lay.cbw; a.nkb = lay.nkb;
     int nb;
     const int lds = fft_lds_bytes_rows(g.fw, &nb);
     a.nb = nb; a.plan = plan; a.tw = tw; a.spec = spec;
@@ -290,14 +312,14 @@ void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
     hipLaunchKernelGGL(fft_rows_kernel, grid, dim3(256), lds, s, a);
 }
 
-void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftPlan& plan,
-                     const float2* tw, double2* part, int* col_blocks_out) {
+void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
+                     const FftPlan& plan, const float2* tw, double2* part) {
+    if (lay.fast_cols && launch_fft_cols_fast(s, spec, n_frames, g, lay, tw, part)) return;
     FftColsArgs a;
     a.spec = spec; a.fh = g.fh; a.fw = g.fw; a.fwh = g.fwh;
-    a.cb = fft_cols_per_block(g.fh);
-    a.nblocks = (g.fwh + a.cb - 1) / a.cb;
+    a.cb = lay.cbw;
+    a.nblocks = lay.nkb;
     a.plan = plan; a.tw = tw; a.part = part;
-    *col_blocks_out = a.nblocks;
     const int lds = 2 * a.cb * g.fh * (int)sizeof(float2);
     dim3 grid(a.nblocks, n_frames);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(256), lds, s, a);
@@ -311,8 +333,10 @@ hipError_t fft_set_lds_limits() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_MAX);
+    if (e != hipSuccess) return e;
+    return fft_fast_init();
 }
 
 }  // namespace stx

@@ -1,0 +1,465 @@
+// Wave-autonomous LDS FFT for the common video / crop sizes.
+//
+// One wave owns one transform (or, for short transforms, 64/LPT of them): it loads the
+// signal into its own LDS slice, runs at most four Stockham passes whose radix-R butterflies
+// (R up to 16, built at compile time from radix 2/3/4/5 kernels) live entirely in registers,
+// and consumes the result — with no workgroup barrier anywhere, because a wave's LDS
+// operations execute in issue order.  Each pass reads all of its inputs into registers before
+// it writes anything, so a single LDS buffer per transform suffices.
+//
+// rows:  two image rows per complex transform, split into the two half spectra, written in a
+//        column-blocked layout [kb][y][CBW] so that the column pass reads contiguous memory;
+// cols:  a workgroup of CBW waves loads one column block (contiguous), each wave transforms
+//        one column and reduces ln(|F|+1) to a (sum, sum of squares) pair.
+#include "stx_internal.h"
+
+namespace stx {
+namespace fastfft {
+
+// ---------------------------------------------------------------- compile-time twiddles
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+constexpr double ct_sin(double x) {
+    double term = x, sum = x;
+    for (int i = 1; i < 30; ++i) {
+        term *= -x * x / (double)((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double ct_cos(double x) {
+    double term = 1.0, sum = 1.0;
+    for (int i = 1; i < 30; ++i) {
+        term *= -x * x / (double)((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+
+template <int R>
+struct Tw {
+    float re[R];
+    float im[R];
+};
+// w^m = exp(-2 pi i m / R)
+template <int R>
+constexpr Tw<R> make_tw() {
+    Tw<R> t{};
+    for (int m = 0; m < R; ++m) {
+        const int mm = (2 * m > R) ? m - R : m;
+        const double ang = -2.0 * kPi * (double)mm / (double)R;
+        t.re[m] = (float)ct_cos(ang);
+        t.im[m] = (float)ct_sin(ang);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// v * exp(-2 pi i m / R) for compile-time-foldable m
+template <int R>
+__device__ __forceinline__ float2 mul_tw(float2 v, int m, const Tw<R>& tw) {
+    if (m == 0) return v;
+    if (4 * m == R) return make_float2(v.y, -v.x);
+    if (2 * m == R) return make_float2(-v.x, -v.y);
+    if (4 * m == 3 * R) return make_float2(-v.y, v.x);
+    return make_float2(v.x * tw.re[m] - v.y * tw.im[m], v.x * tw.im[m] + v.y * tw.re[m]);
+}
+
+// ---------------------------------------------------------------- register DFTs
+template <int R>
+struct Split {
+    static constexpr int A = (R % 4 == 0 && R > 4) ? 4 : (R % 3 == 0 && R > 3) ? 3 : (R % 2 == 0 && R > 2) ? 2 : (R % 5 == 0 && R > 5) ? 5 : 1;
+};
+
+template <int R>
+struct Dft {
+    // R = A*B Cooley-Tukey in registers: B-point transforms over stride-A subsequences,
+    // constant twiddles, then A-point transforms; output in natural order.
+    static __device__ __forceinline__ void run(float2 (&v)[R]) {
+        constexpr int A = Split<R>::A, B = R / A;
+        static_assert(A > 1 && B > 1, "unsupported radix");
+        constexpr Tw<R> tw = make_tw<R>();
+        float2 y[R];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float2 t[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) t[b] = v[a + A * b];
+            Dft<B>::run(t);
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) y[a + A * kb] = mul_tw<R>(t[kb], a * kb, tw);
+        }
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) {
+            float2 t[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) t[a] = y[a + A * kb];
+            Dft<A>::run(t);
+#pragma unroll
+            for (int ka = 0; ka < A; ++ka) v[kb + B * ka] = t[ka];
+        }
+    }
+};
+template <>
+struct Dft<1> {
+    static __device__ __forceinline__ void run(float2 (&)[1]) {}
+};
+template <>
+struct Dft<2> {
+    static __device__ __forceinline__ void run(float2 (&v)[2]) {
+        const float2 a = v[0], b = v[1];
+        v[0] = make_float2(a.x + b.x, a.y + b.y);
+        v[1] = make_float2(a.x - b.x, a.y - b.y);
+    }
+};
+template <>
+struct Dft<3> {
+    static __device__ __forceinline__ void run(float2 (&v)[3]) {
+        const float c = 0.86602540378443864676f;
+        const float2 s = make_float2(v[1].x + v[2].x, v[1].y + v[2].y);
+        const float2 d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
+        const float2 h = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
+        const float2 r = make_float2(c * d.y, -c * d.x);
+        v[0] = make_float2(v[0].x + s.x, v[0].y + s.y);
+        v[1] = make_float2(h.x + r.x, h.y + r.y);
+        v[2] = make_float2(h.x - r.x, h.y - r.y);
+    }
+};
+template <>
+struct Dft<4> {
+    static __device__ __forceinline__ void run(float2 (&v)[4]) {
+        const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
+        const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+        const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
+        const float2 d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+        const float2 a3 = make_float2(d.y, -d.x);
+        v[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+        v[1] = make_float2(a1.x + a3.x, a1.y + a3.y);
+        v[2] = make_float2(a0.x - a2.x, a0.y - a2.y);
+        v[3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+    }
+};
+template <>
+struct Dft<5> {
+    static __device__ __forceinline__ void run(float2 (&v)[5]) {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y);
+        const float2 b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
+        const float2 p1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+        const float2 p2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        const float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+        const float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+        const float2 q1 = make_float2(u1.y, -u1.x), q2 = make_float2(u2.y, -u2.x);
+        v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        v[1] = make_float2(p1.x + q1.x, p1.y + q1.y);
+        v[2] = make_float2(p2.x + q2.x, p2.y + q2.y);
+        v[3] = make_float2(p2.x - q2.x, p2.y - q2.y);
+        v[4] = make_float2(p1.x - q1.x, p1.y - q1.y);
+    }
+};
+
+// ---------------------------------------------------------------- plans
+// N = R0*R1*R2*R3 (unused radices are 1); LPT = lanes per transform (16, 32 or 64)
+template <int N_, int R0_, int R1_, int R2_, int R3_, int LPT_>
+struct Plan {
+    static constexpr int N = N_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_, LPT = LPT_;
+    static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
+    static constexpr int TPW = 64 / LPT_;                    // transforms per wave
+    static constexpr int S = (N_ + (N_ >> 4) + 1) | 1;      // LDS elements per transform (padded, odd)
+};
+
+__device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+
+// One Stockham pass of radix R; NS = product of the radices already applied.
+template <int N, int R, int NS, int LPT>
+__device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t) {
+    if constexpr (R > 1) {
+        constexpr int M = N / R;
+        constexpr int ITER = (M + LPT - 1) / LPT;
+        float2 v[ITER][R];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int j = t + it * LPT;
+            if (ITER * LPT == M || j < M) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[it][r] = buf[pad(j + r * M)];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int j = t + it * LPT;
+            if (ITER * LPT == M || j < M) {
+                const int k = (NS > 1) ? (j % NS) : 0;
+                if constexpr (NS > 1) {
+                    // w^(r k), w = exp(-2 pi i / (NS R)): one table read, the other powers by products
+                    float2 w[R];
+                    w[1] = twg[k * (N / (NS * R))];
+#pragma unroll
+                    for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[it][r] = cmulf(v[it][r], w[r]);
+                }
+                Dft<R>::run(v[it]);
+                const int o = (j - k) * R + k;
+#pragma unroll
+                for (int r = 0; r < R; ++r) buf[pad(o + r * NS)] = v[it][r];
+            }
+        }
+    }
+}
+
+template <class P>
+__device__ __forceinline__ void transform(float2* buf, const float2* twg, int t) {
+    pass<P::N, P::R0, 1, P::LPT>(buf, twg, t);
+    pass<P::N, P::R1, P::R0, P::LPT>(buf, twg, t);
+    pass<P::N, P::R2, P::R0 * P::R1, P::LPT>(buf, twg, t);
+    pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT>(buf, twg, t);
+}
+
+// ---------------------------------------------------------------- kernels
+struct RowsArgs {
+    const uint8_t* gray;
+    int gpitch, grows;
+    int foy, fox, fh, fwh;
+    int cbw, nkb;  // column-block width and count of the spectrum layout
+    const float2* tw;
+    float2* spec;
+};
+
+template <class P>
+__global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
+    __shared__ float2 lds[P::TPW * P::S];
+    constexpr int N = P::N, LPT = P::LPT;
+    const int lane = threadIdx.x;
+    const int sub = lane / LPT, t = lane % LPT;
+    const int frame = blockIdx.y;
+    const int tr = blockIdx.x * P::TPW + sub;  // row pair
+    const int ra = 2 * tr, rb = ra + 1;
+    float2* buf = lds + sub * P::S;
+    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
+    const uint8_t* pa = gp + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
+    const uint8_t* pb = pa + a.gpitch;
+    const bool ina = ra < a.fh, inb = rb < a.fh;
+    if ((N % 4 == 0) && ((a.fox & 3) == 0)) {
+        for (int x4 = t; x4 < N / 4; x4 += LPT) {
+            const uint32_t wa = ina ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
+            const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : 0x80808080u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                buf[pad(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
+                                                   (float)((int)((wb >> (8 * q)) & 255u) - 128));
+        }
+    } else {
+        for (int x = t; x < N; x += LPT)
+            buf[pad(x)] = make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
+    }
+    transform<P>(buf, a.tw, t);
+    if (!ina) return;
+    // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
+    const int cbw = a.cbw;
+    float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw;
+    for (int k = t; k <= N / 2; k += LPT) {
+        const float2 zk = buf[pad(k)];
+        const float2 zc = buf[pad(k ? N - k : 0)];
+        const int kb = k / cbw, kc = k - kb * cbw;
+        float2* o = base + ((int64_t)kb * a.fh + ra) * cbw + kc;
+        o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    }
+}
+
+struct ColsArgs {
+    const float2* spec;
+    int fw, fwh;
+    int cbw, nkb;
+    const float2* tw;
+    double2* part;  // [frame][nkb*cbw]
+};
+
+// blockDim.x = 64 * cbw / TPW ; dynamic LDS = cbw * S float2
+template <class P>
+__global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
+    extern __shared__ float2 dynlds[];
+    constexpr int N = P::N, LPT = P::LPT, S = P::S;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int frame = blockIdx.y, kb = blockIdx.x;
+    const int cbw = a.cbw;
+    // the block [N][cbw] is contiguous in global memory
+    const float2* src = a.spec + ((int64_t)frame * a.nkb + kb) * (int64_t)N * cbw;
+    if (cbw >= 2) {
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        const int half = cbw >> 1;
+        for (int e = tid; e < N * half; e += nthreads) {
+            const float4 q = src4[e];
+            const int y = e / half, c = 2 * (e - y * half);
+            dynlds[c * S + pad(y)] = make_float2(q.x, q.y);
+            dynlds[(c + 1) * S + pad(y)] = make_float2(q.z, q.w);
+        }
+    } else {
+        for (int y = tid; y < N; y += nthreads) dynlds[pad(y)] = src[y];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sub = lane / LPT, t = lane % LPT;
+    const int c = wave * P::TPW + sub;  // column within the block
+    float2* buf = dynlds + c * S;
+    const int k = kb * cbw + c;
+    transform<P>(buf, a.tw, t);
+    double ls = 0.0, ls2 = 0.0;
+    if (k < a.fwh) {
+        const float dc_fix = 128.0f * (float)N * (float)a.fw;
+        for (int y = t; y < N; y += LPT) {
+            float2 v = buf[pad(y)];
+            if (k == 0 && y == 0) v.x += dc_fix;
+            const float mag = sqrtf(v.x * v.x + v.y * v.y);
+            const double l = (double)logf(mag + 1.0f);
+            ls += l;
+            ls2 += l * l;
+        }
+    }
+#pragma unroll
+    for (int o = LPT / 2; o > 0; o >>= 1) {
+        ls += __shfl_xor(ls, o, 64);
+        ls2 += __shfl_xor(ls2, o, 64);
+    }
+    if (t == 0) {
+        // columns 0 and (even W) W/2 are their own mirror images; every other column stands for two
+        const double wgt = (k >= a.fwh) ? 0.0 : ((k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0);
+        a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = make_double2(wgt * ls, wgt * ls2);
+    }
+}
+
+// ---------------------------------------------------------------- size table
+#define STX_FFT_SIZES(X)      \
+    X(64, 8, 8, 1, 1, 16)     \
+    X(80, 10, 8, 1, 1, 16)    \
+    X(96, 12, 8, 1, 1, 16)    \
+    X(128, 16, 8, 1, 1, 16)   \
+    X(160, 16, 10, 1, 1, 16)  \
+    X(240, 16, 15, 1, 1, 16)  \
+    X(256, 16, 16, 1, 1, 16)  \
+    X(320, 8, 8, 5, 1, 64)    \
+    X(360, 9, 8, 5, 1, 64)    \
+    X(480, 10, 8, 6, 1, 64)   \
+    X(512, 8, 8, 8, 1, 64)    \
+    X(540, 10, 9, 6, 1, 64)   \
+    X(640, 10, 8, 8, 1, 64)   \
+    X(720, 10, 9, 8, 1, 64)   \
+    X(768, 12, 8, 8, 1, 64)   \
+    X(960, 12, 10, 8, 1, 64)  \
+    X(1024, 16, 8, 8, 1, 64)  \
+    X(1080, 12, 10, 9, 1, 64) \
+    X(1280, 16, 10, 8, 1, 64) \
+    X(1440, 12, 12, 10, 1, 64) \
+    X(1920, 16, 12, 10, 1, 64) \
+    X(2048, 16, 16, 8, 1, 64)
+
+template <class P>
+void launch_rows_t(hipStream_t s, const RowsArgs& a, int n_frames) {
+    const int pairs = (a.fh + 1) / 2;
+    dim3 grid((pairs + P::TPW - 1) / P::TPW, n_frames);
+    hipLaunchKernelGGL(rows_kernel<P>, grid, dim3(64), 0, s, a);
+}
+
+template <class P>
+void launch_cols_t(hipStream_t s, const ColsArgs& a, int n_frames) {
+    const int waves = (a.cbw + P::TPW - 1) / P::TPW;
+    dim3 grid(a.nkb, n_frames);
+    hipLaunchKernelGGL(cols_kernel<P>, grid, dim3(64 * waves), (size_t)a.cbw * P::S * sizeof(float2), s, a);
+}
+
+template <class P>
+hipError_t set_cols_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(cols_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               159 * 1024);
+}
+
+}  // namespace fastfft
+
+using namespace fastfft;
+
+bool fft_fast_available(int n) {
+    switch (n) {
+#define X(N, A, B, C, D, L) case N:
+        STX_FFT_SIZES(X)
+#undef X
+        return true;
+        default:
+            return false;
+    }
+}
+
+// LDS elements per transform of the fast column kernel (0 if the size has no fast kernel)
+int fft_fast_stride(int n) {
+    switch (n) {
+#define X(N, A, B, C, D, L) \
+    case N:                 \
+        return Plan<N, A, B, C, D, L>::S;
+        STX_FFT_SIZES(X)
+#undef X
+        default:
+            return 0;
+    }
+}
+
+int fft_fast_tpw(int n) {
+    switch (n) {
+#define X(N, A, B, C, D, L) \
+    case N:                 \
+        return Plan<N, A, B, C, D, L>::TPW;
+        STX_FFT_SIZES(X)
+#undef X
+        default:
+            return 0;
+    }
+}
+
+hipError_t fft_fast_init() {
+    hipError_t e = hipSuccess;
+#define X(N, A, B, C, D, L)                          \
+    e = set_cols_lds<Plan<N, A, B, C, D, L>>();      \
+    if (e != hipSuccess) return e;
+    STX_FFT_SIZES(X)
+#undef X
+    return e;
+}
+
+bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
+                          const float2* tw, float2* spec) {
+    RowsArgs a;
+    a.gray = gray; a.gpitch = g.gpitch; a.grows = g.grows;
+    a.foy = g.foy; a.fox = g.fox; a.fh = g.fh; a.fwh = g.fwh;
+    a.cbw = lay.cbw; a.nkb = lay.nkb; a.tw = tw; a.spec = spec;
+    switch (g.fw) {
+#define X(N, A, B, C, D, L)                                    \
+    case N:                                                    \
+        launch_rows_t<Plan<N, A, B, C, D, L>>(s, a, n_frames); \
+        return true;
+        STX_FFT_SIZES(X)
+#undef X
+        default:
+            return false;
+    }
+}
+
+bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
+                          const float2* tw, double2* part) {
+    ColsArgs a;
+    a.spec = spec; a.fw = g.fw; a.fwh = g.fwh; a.cbw = lay.cbw; a.nkb = lay.nkb; a.tw = tw; a.part = part;
+    switch (g.fh) {
+#define X(N, A, B, C, D, L)                                    \
+    case N:                                                    \
+        launch_cols_t<Plan<N, A, B, C, D, L>>(s, a, n_frames); \
+        return true;
+        STX_FFT_SIZES(X)
+#undef X
+        default:
+            return false;
+    }
+}
+
+}  // namespace stx

@@ -71,14 +71,28 @@ void launch_edge_count(hipStream_t s, const uint32_t* tile_count, int n_frames, 
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);
 
 // Real 2-D FFT of the (cropped) gray plane minus 128, log-magnitude statistics.
-// spec: [n_frames][fh][fwh] float2 intermediate.  part: [n_frames][col_blocks] double2.
-int fft_lds_bytes_rows(int n, int* nb_out);
-void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftPlan& plan,
-                     const float2* tw, float2* spec);
-int fft_cols_per_block(int n);
-void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftPlan& plan,
-                     const float2* tw, double2* part, int* col_blocks_out);
-void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int col_blocks, FrameAcc* acc);
+// spec: [n_frames][nkb][fh][cbw] float2 half spectrum in column blocks.
+// part: [n_frames][parts_per_frame] double2 partial (sum, sum of squares).
+struct FftLayout {
+    int cbw, nkb;
+    int parts_per_frame;
+    bool fast_rows, fast_cols;
+};
+FftLayout fft_choose_layout(const Geom& g);
+void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
+                     const FftPlan& plan, const float2* tw, float2* spec);
+void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
+                     const FftPlan& plan, const float2* tw, double2* part);
+void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int parts_per_frame, FrameAcc* acc);
+// compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
+bool fft_fast_available(int n);
+int fft_fast_stride(int n);
+int fft_fast_tpw(int n);
+hipError_t fft_fast_init();
+bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
+                          const float2* tw, float2* spec);
+bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
+                          const float2* tw, double2* part);
 
 void launch_synth(hipStream_t s, uint8_t* bgr, int kind, uint64_t seed, uint32_t video, uint32_t frame0, int n_frames,
                   int h, int w);
