@@ -18,7 +18,8 @@ using namespace stx;
 namespace {
 
 constexpr int HYST_MAX_PASSES = 8192;
-constexpr int HYST_GROUP = 4;  // passes issued between two host checks of the "changed" counter
+constexpr int HYST_FIRST_PASSES = 8;  // hysteresis passes queued with every chunk
+constexpr int HYST_GROUP = 4;         // further passes per host check when the first batch was not enough
 
 struct DevBuf {
     void* p = nullptr;
@@ -33,19 +34,30 @@ struct TimedSpan {
 
 }  // namespace
 
+// One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
+// i+1 while the device still works on chunk i.
+struct Slot {
+    DevBuf gray, strong, cand, spec, part, tiles, spart, acc, changed, staging;
+    FrameAcc* acc_host = nullptr;  // pinned
+    size_t acc_host_cap = 0;
+    unsigned int* changed_host = nullptr;  // pinned, one word
+    hipEvent_t done = nullptr;
+    int passes = 0;  // hysteresis passes queued so far
+    int F = 0;
+    std::vector<TimedSpan> spans;
+};
+constexpr int N_SLOTS = 2;
+
 struct stx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    DevBuf gray, strong, cand, spec, part, tiles, acc, changed, staging, codes, plane;
-    FrameAcc* acc_host = nullptr;  // pinned
-    size_t acc_host_cap = 0;
-    unsigned int* changed_host = nullptr;  // pinned, HYST_MAX_PASSES entries
+    Slot slot[N_SLOTS];
+    DevBuf codes, plane;
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
     bool timing = false;
     stx_timing tacc;
-    std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> event_pool;
 };
 
@@ -91,12 +103,13 @@ hipEvent_t get_event(stx_ctx* c) {
     return e;
 }
 
-// RAII-less span helpers: begin/end bracket kernel launches of one family on the context stream.
+// begin/end bracket kernel launches of one family on the context stream
 struct Span {
     stx_ctx* c;
+    std::vector<TimedSpan>* dst;
     TimedSpan t;
     bool on;
-    Span(stx_ctx* c_, int kind, int launches) : c(c_), on(c_->timing) {
+    Span(stx_ctx* c_, std::vector<TimedSpan>* dst_, int kind, int launches) : c(c_), dst(dst_), on(c_->timing) {
         if (!on) return;
         t.kind = kind;
         t.launches = launches;
@@ -108,12 +121,13 @@ struct Span {
     void end() {
         if (!on) return;
         (void)hipEventRecord(t.e1, c->stream);
-        c->spans.push_back(t);
+        dst->push_back(t);
     }
 };
 
-void collect_spans(stx_ctx* c) {
-    for (auto& t : c->spans) {
+// call only after the stream has passed the spans' end events
+void collect_spans(stx_ctx* c, std::vector<TimedSpan>& spans) {
+    for (auto& t : spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
             c->tacc.ms[t.kind] += ms;
@@ -122,7 +136,7 @@ void collect_spans(stx_ctx* c) {
         c->event_pool.push_back(t.e0);
         c->event_pool.push_back(t.e1);
     }
-    c->spans.clear();
+    spans.clear();
 }
 
 int get_twiddles(stx_ctx* c, int n, float2** out) {
@@ -243,106 +257,10 @@ struct ChunkOpts {
     uint8_t* codes = nullptr;  // device, optional [F][H][W]
 };
 
-// Runs the whole path for F frames resident on the device and leaves the reductions in
-// c->acc_host[0..F).
-int run_chunk(stx_ctx* c, const uint8_t* bgr_dev, int64_t row_stride, int64_t frame_stride, int F, const Geom& g,
-              const stx_params& p, const FftPlan& plan_w, const FftPlan& plan_h, const float2* tw_w, const float2* tw_h,
-              const LbpOffsets& off, const ChunkOpts& opts) {
-    hipStream_t s = c->stream;
-    int rc;
-    if ((rc = ensure(c, c->gray, (size_t)F * g.grows * g.gpitch)) != STX_OK) return rc;
-    const size_t bm = (size_t)F * g.H * g.wpr * sizeof(unsigned long long);
-    if ((rc = ensure(c, c->strong, bm)) != STX_OK) return rc;
-    if ((rc = ensure(c, c->cand, bm)) != STX_OK) return rc;
-    const FftLayout lay = fft_choose_layout(g);
-    if ((rc = ensure(c, c->spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
-    if ((rc = ensure(c, c->part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
-    if ((rc = ensure(c, c->tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
-    if ((rc = ensure(c, c->acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
-    if ((rc = ensure(c, c->changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
-    if ((size_t)F > c->acc_host_cap) {
-        if (c->acc_host) HIPCHK(c, hipHostFree(c->acc_host));
-        c->acc_host = nullptr;
-        c->acc_host_cap = 0;
-        HIPCHK(c, hipHostMalloc((void**)&c->acc_host, sizeof(FrameAcc) * (size_t)F * 2, hipHostMallocDefault));
-        c->acc_host_cap = (size_t)F * 2;
-    }
-    FrameAcc* acc = (FrameAcc*)c->acc.p;
-    unsigned int* changed = (unsigned int*)c->changed.p;
-    unsigned long long* strong = (unsigned long long*)c->strong.p;
-    unsigned long long* cand = (unsigned long long*)c->cand.p;
-    uint32_t* tiles = (uint32_t*)c->tiles.p;
-
-    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
-    HIPCHK(c, hipMemsetAsync(changed, 0, (size_t)HYST_MAX_PASSES * sizeof(unsigned int), s));
-
-    {
-        Span sp(c, STX_K_GRAY, 1);
-        launch_gray(s, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)c->gray.p, acc);
-        sp.end();
-    }
-    const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
-    {
-        Span sp(c, STX_K_STENCIL, 1);
-        launch_stencil(s, (const uint8_t*)c->gray.p, F, g, lbp81, off, p.canny_low, p.canny_high, acc, strong, cand,
-                       lbp81 ? opts.codes : nullptr);
-        sp.end();
-    }
-    if (!lbp81) {
-        Span sp(c, STX_K_LBP_GENERIC, 1);
-        launch_lbp_generic(s, (const uint8_t*)c->gray.p, F, g, p.lbp_points, off, 0, acc, opts.codes);
-        sp.end();
-    }
-    // first group of hysteresis passes; the FFT is queued behind it so the host's wait for the
-    // "changed" counter overlaps device work
-    int pass = 0;
-    auto hyst_group = [&]() -> int {
-        Span sp(c, STX_K_HYST, HYST_GROUP);
-        for (int i = 0; i < HYST_GROUP; ++i, ++pass) launch_hyst_pass(s, strong, cand, F, g, changed, pass, tiles);
-        sp.end();
-        HIPCHK(c, hipMemcpyAsync(c->changed_host, changed + (pass - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-        return STX_OK;
-    };
-    if ((rc = hyst_group()) != STX_OK) return rc;
-    {
-        Span sp(c, STX_K_FFT_ROWS, 1);
-        launch_fft_rows(s, (const uint8_t*)c->gray.p, F, g, lay, plan_w, tw_w, (float2*)c->spec.p);
-        sp.end();
-    }
-    {
-        Span sp(c, STX_K_FFT_COLS, 1);
-        launch_fft_cols(s, (const float2*)c->spec.p, F, g, lay, plan_h, tw_h, (double2*)c->part.p);
-        sp.end();
-    }
-    {
-        Span sp(c, STX_K_REDUCE, 1);
-        launch_fft_reduce(s, (const double2*)c->part.p, F, lay.parts_per_frame, acc);
-        sp.end();
-    }
-    HIPCHK(c, hipStreamSynchronize(s));
-    while (*c->changed_host != 0) {
-        if (pass + HYST_GROUP > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
-        if ((rc = hyst_group()) != STX_OK) return rc;
-        HIPCHK(c, hipStreamSynchronize(s));
-    }
-    {
-        Span sp(c, STX_K_REDUCE, 1);
-        launch_edge_count(s, tiles, F, g, acc);
-        sp.end();
-    }
-    HIPCHK(c, hipMemcpyAsync(c->acc_host, acc, (size_t)F * sizeof(FrameAcc), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipGetLastError());
-    if (c->timing) {
-        collect_spans(c);
-        c->tacc.frames += (uint64_t)F;
-    }
-    return STX_OK;
-}
-
 struct Prepared {
     stx_params p;
     Geom g;
+    FftLayout lay;
     FftPlan plan_w, plan_h;
     float2 *tw_w, *tw_h;
     LbpOffsets off;
@@ -357,23 +275,143 @@ int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!make_fft_plan(pr->g.fw, &pr->plan_w) || !make_fft_plan(pr->g.fh, &pr->plan_h))
         return fail(c, STX_ERR_UNSUPPORTED, "FFT size has too many prime factors");
+    pr->lay = fft_choose_layout(pr->g);
     if ((rc = get_twiddles(c, pr->g.fw, &pr->tw_w)) != STX_OK) return rc;
     if ((rc = get_twiddles(c, pr->g.fh, &pr->tw_h)) != STX_OK) return rc;
     if (lbp_offsets(pr->p.lbp_points, pr->p.lbp_radius, &pr->off) != 0) return fail(c, STX_ERR_INVALID, "bad lbp_points");
     return STX_OK;
 }
 
+int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g) {
+    if (sl.passes + n > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
+    Span sp(c, &sl.spans, STX_K_HYST, n);
+    for (int i = 0; i < n; ++i, ++sl.passes)
+        launch_hyst_pass(c->stream, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
+                         (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p);
+    sp.end();
+    return STX_OK;
+}
+
+int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
+    hipStream_t s = c->stream;
+    const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
+    {
+        Span sp(c, &sl.spans, STX_K_REDUCE, 1);
+        launch_frame_reduce(s, (const uint32_t*)sl.spart.p, lbp81, (const uint32_t*)sl.tiles.p, (const double2*)sl.part.p,
+                            pr.lay.parts_per_frame, sl.F, pr.g, (FrameAcc*)sl.acc.p);
+        sp.end();
+    }
+    HIPCHK(c, hipMemcpyAsync(sl.changed_host, (unsigned int*)sl.changed.p + (sl.passes - 1), sizeof(unsigned int),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(sl.acc_host, sl.acc.p, (size_t)sl.F * sizeof(FrameAcc), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(sl.done, s));
+    return STX_OK;
+}
+
+// Queues the whole path for F device-resident frames on the context stream; returns without
+// waiting.  finish_chunk() waits and leaves the reductions in sl.acc_host[0..F).
+int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stride, int64_t frame_stride, int F,
+                  const Prepared& pr, const ChunkOpts& opts) {
+    hipStream_t s = c->stream;
+    const Geom& g = pr.g;
+    const stx_params& p = pr.p;
+    const FftLayout& lay = pr.lay;
+    int rc;
+    if ((rc = ensure(c, sl.gray, (size_t)F * g.grows * g.gpitch)) != STX_OK) return rc;
+    const size_t bm = (size_t)F * g.H * g.wpr * sizeof(unsigned long long);
+    if ((rc = ensure(c, sl.strong, bm)) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.cand, bm)) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.spart, (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
+    if ((size_t)F > sl.acc_host_cap) {
+        if (sl.acc_host) HIPCHK(c, hipHostFree(sl.acc_host));
+        sl.acc_host = nullptr;
+        sl.acc_host_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&sl.acc_host, sizeof(FrameAcc) * (size_t)F * 2, hipHostMallocDefault));
+        sl.acc_host_cap = (size_t)F * 2;
+    }
+    sl.F = F;
+    sl.passes = 0;
+    FrameAcc* acc = (FrameAcc*)sl.acc.p;
+    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
+    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
+    {
+        Span sp(c, &sl.spans, STX_K_GRAY, 1);
+        launch_gray(s, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)sl.gray.p);
+        sp.end();
+    }
+    const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
+    {
+        Span sp(c, &sl.spans, STX_K_STENCIL, 1);
+        launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
+                       (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr);
+        sp.end();
+    }
+    if (!lbp81) {
+        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 1);
+        launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, 0, acc, opts.codes);
+        sp.end();
+    }
+    // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
+    // changed nothing); finish_chunk() checks the last counter and only then adds more
+    if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
+    {
+        Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1);
+        launch_fft_rows(s, (const uint8_t*)sl.gray.p, F, g, lay, pr.plan_w, pr.tw_w, (float2*)sl.spec.p);
+        sp.end();
+    }
+    {
+        Span sp(c, &sl.spans, STX_K_FFT_COLS, 1);
+        launch_fft_cols(s, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h, (double2*)sl.part.p);
+        sp.end();
+    }
+    return queue_results(c, sl, pr);
+}
+
+int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out) {
+    HIPCHK(c, hipEventSynchronize(sl.done));
+    while (*sl.changed_host != 0) {
+        // rare: long contours still growing after the first batch of passes
+        int rc;
+        const int more = HYST_GROUP;
+        if (sl.passes + more > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
+        HIPCHK(c, hipMemsetAsync((unsigned int*)sl.changed.p + sl.passes, 0, (size_t)more * sizeof(unsigned int), c->stream));
+        if ((rc = hyst_passes(c, sl, more, pr.g)) != STX_OK) return rc;
+        if ((rc = queue_results(c, sl, pr)) != STX_OK) return rc;
+        HIPCHK(c, hipEventSynchronize(sl.done));
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->timing) {
+        collect_spans(c, sl.spans);
+        c->tacc.frames += (uint64_t)sl.F;
+    }
+    if (out)
+        for (int i = 0; i < sl.F; ++i) finalize(sl.acc_host[i], pr.g, pr.p.lbp_points, out + i);
+    return STX_OK;
+}
+
 int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_t row_stride, int64_t frame_stride,
                         const Prepared& pr, stx_metrics* out) {
     const int chunk = pick_chunk(c, pr.g, n_frames);
-    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+    int prev_slot = -1, prev_f0 = 0, k = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk, ++k) {
         const int F = std::min(chunk, n_frames - f0);
+        Slot& sl = c->slot[k % N_SLOTS];
         ChunkOpts o;
-        int rc = run_chunk(c, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr.g, pr.p, pr.plan_w,
-                           pr.plan_h, pr.tw_w, pr.tw_h, pr.off, o);
-        if (rc != STX_OK) return rc;
-        for (int i = 0; i < F; ++i) finalize(c->acc_host[i], pr.g, pr.p.lbp_points, out + f0 + i);
+        int rc = enqueue_chunk(c, sl, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr, o);
+        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+        if (rc != STX_OK) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        prev_slot = k % N_SLOTS;
+        prev_f0 = f0;
     }
+    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
     return STX_OK;
 }
 
@@ -416,19 +454,21 @@ int stx_create(int device_id, stx_ctx** out) {
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
     if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
-    if (e == hipSuccess) {
+    for (int i = 0; i < N_SLOTS && e == hipSuccess; ++i) {
         step = "hipHostMalloc";
-        e = hipHostMalloc((void**)&c->changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
+        e = hipHostMalloc((void**)&c->slot[i].changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
+        if (e == hipSuccess) {
+            *c->slot[i].changed_host = 0;
+            step = "hipEventCreate";
+            e = hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming);
+        }
     }
     if (e == hipSuccess) { step = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; e = fft_set_lds_limits(); }
     if (e != hipSuccess) {
         g_create_err = std::string(step) + ": " + hipGetErrorString(e);
-        if (c->stream) (void)hipStreamDestroy(c->stream);
-        if (c->changed_host) (void)hipHostFree(c->changed_host);
-        delete c;
+        stx_destroy(c);
         return STX_ERR_HIP;
     }
-    *c->changed_host = 0;
     *out = c;
     return STX_OK;
 }
@@ -437,14 +477,18 @@ int stx_destroy(stx_ctx* c) {
     if (!c) return STX_ERR_INVALID;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->gray, &c->strong, &c->cand, &c->spec, &c->part, &c->tiles, &c->acc, &c->changed,
-                      &c->staging, &c->codes, &c->plane};
-    for (DevBuf* b : bufs)
-        if (b->p) (void)hipFree(b->p);
+    for (Slot& sl : c->slot) {
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
+        for (DevBuf* b : bufs)
+            if (b->p) (void)hipFree(b->p);
+        if (sl.acc_host) (void)hipHostFree(sl.acc_host);
+        if (sl.changed_host) (void)hipHostFree(sl.changed_host);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        for (auto& t : sl.spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    }
+    if (c->codes.p) (void)hipFree(c->codes.p);
+    if (c->plane.p) (void)hipFree(c->plane.p);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
-    if (c->acc_host) (void)hipHostFree(c->acc_host);
-    if (c->changed_host) (void)hipHostFree(c->changed_host);
-    for (auto& t : c->spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -483,21 +527,40 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
     const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
     const int64_t dframe = dpitch * h;
     const int chunk = pick_chunk(c, pr.g, n_frames);
-    if ((rc = ensure(c, c->staging, (size_t)chunk * dframe)) != STX_OK) return rc;
-    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+    const bool dense = !list && row_stride == (int64_t)3 * w && dpitch == row_stride && frame_stride == dframe;
+    int prev_slot = -1, prev_f0 = 0, k = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk, ++k) {
         const int F = std::min(chunk, n_frames - f0);
-        for (int i = 0; i < F; ++i) {
-            const uint8_t* src = list ? list[f0 + i] : base + (int64_t)(f0 + i) * frame_stride;
-            if (!src) return fail(c, STX_ERR_INVALID, "null frame pointer");
-            HIPCHK(c, hipMemcpy2DAsync((uint8_t*)c->staging.p + (int64_t)i * dframe, (size_t)dpitch, src, (size_t)row_stride,
-                                       (size_t)3 * w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        Slot& sl = c->slot[k % N_SLOTS];
+        if ((rc = ensure(c, sl.staging, (size_t)chunk * dframe)) != STX_OK) break;
+        if (dense) {
+            rc = STX_OK;
+            hipError_t e = hipMemcpyAsync(sl.staging.p, base + (int64_t)f0 * frame_stride, (size_t)F * dframe,
+                                          hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) rc = fail(c, STX_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+        } else {
+            for (int i = 0; i < F && rc == STX_OK; ++i) {
+                const uint8_t* src = list ? list[f0 + i] : base + (int64_t)(f0 + i) * frame_stride;
+                if (!src) { rc = fail(c, STX_ERR_INVALID, "null frame pointer"); break; }
+                hipError_t e = hipMemcpy2DAsync((uint8_t*)sl.staging.p + (int64_t)i * dframe, (size_t)dpitch, src,
+                                                (size_t)row_stride, (size_t)3 * w, (size_t)h, hipMemcpyHostToDevice,
+                                                c->stream);
+                if (e != hipSuccess) rc = fail(c, STX_ERR_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e));
+            }
         }
+        if (rc != STX_OK) break;
         ChunkOpts o;
-        rc = run_chunk(c, (const uint8_t*)c->staging.p, dpitch, dframe, F, pr.g, pr.p, pr.plan_w, pr.plan_h, pr.tw_w,
-                       pr.tw_h, pr.off, o);
-        if (rc != STX_OK) return rc;
-        for (int i = 0; i < F; ++i) finalize(c->acc_host[i], pr.g, pr.p.lbp_points, out + f0 + i);
+        rc = enqueue_chunk(c, sl, (const uint8_t*)sl.staging.p, dpitch, dframe, F, pr, o);
+        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+        if (rc != STX_OK) break;
+        prev_slot = k % N_SLOTS;
+        prev_f0 = f0;
     }
+    if (rc != STX_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
     return STX_OK;
 }
 
@@ -557,23 +620,23 @@ int stx_debug_planes(stx_ctx* c, const uint8_t* bgr, int h, int w, int64_t row_s
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
     const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
-    if ((rc = ensure(c, c->staging, (size_t)dpitch * h)) != STX_OK) return rc;
+    Slot& sl = c->slot[0];
+    if ((rc = ensure(c, sl.staging, (size_t)dpitch * h)) != STX_OK) return rc;
     if ((rc = ensure(c, c->codes, (size_t)h * w)) != STX_OK) return rc;
     if ((rc = ensure(c, c->plane, (size_t)h * w)) != STX_OK) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(c->staging.p, (size_t)dpitch, bgr, (size_t)row_stride, (size_t)3 * w, (size_t)h,
+    HIPCHK(c, hipMemcpy2DAsync(sl.staging.p, (size_t)dpitch, bgr, (size_t)row_stride, (size_t)3 * w, (size_t)h,
                                hipMemcpyHostToDevice, c->stream));
     ChunkOpts o;
     o.codes = (uint8_t*)c->codes.p;
-    rc = run_chunk(c, (const uint8_t*)c->staging.p, dpitch, dpitch * h, 1, pr.g, pr.p, pr.plan_w, pr.plan_h, pr.tw_w,
-                   pr.tw_h, pr.off, o);
-    if (rc != STX_OK) return rc;
+    if ((rc = enqueue_chunk(c, sl, (const uint8_t*)sl.staging.p, dpitch, dpitch * h, 1, pr, o)) != STX_OK) return rc;
+    if ((rc = finish_chunk(c, sl, pr, nullptr)) != STX_OK) return rc;
     if (gray_out)
-        HIPCHK(c, hipMemcpy2DAsync(gray_out, (size_t)w, (const uint8_t*)c->gray.p + (size_t)GRAY_YOFF * pr.g.gpitch + GRAY_XOFF,
+        HIPCHK(c, hipMemcpy2DAsync(gray_out, (size_t)w, (const uint8_t*)sl.gray.p + (size_t)GRAY_YOFF * pr.g.gpitch + GRAY_XOFF,
                                    (size_t)pr.g.gpitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, c->stream));
     if (lbp_codes_out)
         HIPCHK(c, hipMemcpyAsync(lbp_codes_out, c->codes.p, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
     if (edges_out) {
-        launch_edges_expand(c->stream, (const unsigned long long*)c->strong.p, pr.g, (uint8_t*)c->plane.p);
+        launch_edges_expand(c->stream, (const unsigned long long*)sl.strong.p, pr.g, (uint8_t*)c->plane.p);
         HIPCHK(c, hipMemcpyAsync(edges_out, c->plane.p, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -588,12 +651,13 @@ int stx_synth_device(stx_ctx* c, uint8_t* bgr_dev, int kind, uint64_t seed, uint
         return fail(c, STX_ERR_INVALID, "synthetic generator limits: h,w<=8192, frame<1024, video<2^28");
     if (n_frames == 0) return STX_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    Span sp(c, STX_K_SYNTH, 1);
+    std::vector<TimedSpan> spans;
+    Span sp(c, &spans, STX_K_SYNTH, 1);
     launch_synth(c->stream, bgr_dev, kind, seed, video, frame0, n_frames, h, w);
     sp.end();
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
-    if (c->timing) collect_spans(c);
+    collect_spans(c, spans);
     return STX_OK;
 }
 

@@ -223,26 +223,6 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void fft_reduce_kernel(const double2* __restrict__ part, int nblocks,
-                                                        FrameAcc* __restrict__ acc) {
-    const int frame = blockIdx.x;
-    double s = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 64) {
-        const double2 p = part[(int64_t)frame * nblocks + i];
-        s += p.x;
-        s2 += p.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
-    if (threadIdx.x == 0) {
-        acc[frame].fft_sum = s;
-        acc[frame].fft_sumsq = s2;
-    }
-}
-
 bool make_fft_plan(int n, FftPlan* plan) {
     plan->n = n;
     plan->npass = 0;
@@ -323,10 +303,6 @@ void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom
     const int lds = 2 * a.cb * g.fh * (int)sizeof(float2);
     dim3 grid(a.nblocks, n_frames);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(256), lds, s, a);
-}
-
-void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int col_blocks, FrameAcc* acc) {
-    hipLaunchKernelGGL(fft_reduce_kernel, dim3(n_frames), dim3(64), 0, s, part, col_blocks, acc);
 }
 
 hipError_t fft_set_lds_limits() {

@@ -18,39 +18,32 @@ __device__ __forceinline__ uint32_t to_gray(uint32_t b, uint32_t g, uint32_t r, 
                    : ((b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14);
 }
 
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+struct __attribute__((aligned(4))) Bgr4 {
+    uint32_t a, b, c;  // 12 bytes = four BGR pixels
+};
 
+// grid: x = 256-dword column blocks of a padded gray row, y = padded row, z = frame
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ bgr, int64_t row_stride,
                                                    int64_t frame_stride, int H, int W, int gpitch, int grows,
-                                                   int shift15, int aligned4, uint8_t* __restrict__ gray,
-                                                   FrameAcc* __restrict__ acc) {
-    __shared__ unsigned long long wsum[4];
-    const int frame = blockIdx.y;
+                                                   int shift15, int aligned4, uint8_t* __restrict__ gray) {
+    const int frame = blockIdx.z;
+    const int ry = blockIdx.y;
     const int dpr = gpitch >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    unsigned long long local = 0;
-    if (idx < grows * dpr) {
-        const int ry = idx / dpr;
-        const int dc = idx - ry * dpr;
+    const int dc = blockIdx.x * 256 + threadIdx.x;
+    if (dc < dpr) {
         const int sy = reflect101(ry - GRAY_YOFF, H);
         const int x = 4 * dc - GRAY_XOFF;
         const uint8_t* src = bgr + (int64_t)frame * frame_stride + (int64_t)sy * row_stride;
         uint32_t out = 0;
-        const bool counted_row = (ry >= GRAY_YOFF) && (ry < H + GRAY_YOFF);
         if (aligned4 && x >= 0 && x + 3 < W) {
-            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + 3 * x);
-            const uint32_t a = s4[0], b = s4[1], c = s4[2];
+            const Bgr4 v = *reinterpret_cast<const Bgr4*>(src + 3 * x);
+            const uint32_t a = v.a, b = v.b, c = v.c;
             // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3
             const uint32_t g0 = to_gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, shift15);
             const uint32_t g1 = to_gray(a >> 24, b & 255u, (b >> 8) & 255u, shift15);
             const uint32_t g2 = to_gray((b >> 16) & 255u, b >> 24, c & 255u, shift15);
             const uint32_t g3 = to_gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24, shift15);
             out = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-            if (counted_row) local = g0 + g1 + g2 + g3;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -60,28 +53,20 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
                     const uint8_t* p = src + 3 * sx;
                     const uint32_t gv = to_gray(p[0], p[1], p[2], shift15);
                     out |= gv << (8 * j);
-                    if (counted_row && xx >= 0 && xx < W) local += gv;
                 }
             }
         }
-        reinterpret_cast<uint32_t*>(gray + (int64_t)frame * grows * gpitch)[idx] = out;
-    }
-    local = wave_sum_u64(local);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&acc[frame].gray_sum, t);
+        reinterpret_cast<uint32_t*>(gray + ((int64_t)frame * grows + ry) * gpitch)[dc] = out;
     }
 }
 
 void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
-                 const Geom& g, int shift, uint8_t* gray, FrameAcc* acc) {
-    const int total = g.grows * (g.gpitch >> 2);
+                 const Geom& g, int shift, uint8_t* gray) {
+    const int dpr = g.gpitch >> 2;
     const int aligned4 = ((reinterpret_cast<uintptr_t>(bgr) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3u) == 0;
-    dim3 grid((total + 255) / 256, n_frames);
+    dim3 grid((dpr + 255) / 256, g.grows, n_frames);
     hipLaunchKernelGGL(gray_kernel, grid, dim3(256), 0, s, bgr, row_stride, frame_stride, g.H, g.W, g.gpitch, g.grows,
-                       shift == 15 ? 1 : 0, aligned4, gray, acc);
+                       shift == 15 ? 1 : 0, aligned4, gray);
 }
 
 }  // namespace stx

@@ -83,24 +83,64 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
 
     const bool ch = S != orig;
     if (ch) sb[(int64_t)y * wpr + wx] = S;
-    if (__any(ch) && lane == 0) atomicAdd(&changed[pass], 1u);
+    // a flag, not a count: every writer stores the same value, so a plain store is enough
+    if (__any(ch) && lane == 0) changed[pass] = 1u;
     uint32_t cnt = __popcll(S);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (lane == 0) tile_count[((int64_t)frame * htiles_y + ty) * wpr + wx] = cnt;
 }
 
-__global__ __launch_bounds__(256) void edge_count_kernel(const uint32_t* __restrict__ tile_count, int tiles,
-                                                         FrameAcc* __restrict__ acc) {
-    __shared__ uint32_t part[4];
-    const int frame = blockIdx.x;
-    uint32_t s = 0;
-    for (int i = threadIdx.x; i < tiles; i += 256) s += tile_count[(int64_t)frame * tiles + i];
+// Per-frame reduction of everything the other kernels left as partials, in a fixed order
+// (bit-reproducible): stencil tile sums -> LBP histogram / high-pass / residual / gray sums,
+// hysteresis tile counts -> edge count, FFT column partials -> log-magnitude sums.
+__global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __restrict__ spart, int stiles,
+                                                           int lbp_from_tiles, const uint32_t* __restrict__ tile_count,
+                                                           int htiles, const double2* __restrict__ fpart, int nfparts,
+                                                           FrameAcc* __restrict__ acc) {
+    __shared__ unsigned long long red[16][17];
+    __shared__ double dred[2][4];
+    __shared__ uint32_t ered[4];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    // 16 quantities x 16 tile lanes
+    {
+        const int q = tid & 15, lane16 = tid >> 4;
+        unsigned long long s = 0;
+        for (int t = lane16; t < stiles; t += 16) s += spart[((int64_t)frame * stiles + t) * 16 + q];
+        red[q][lane16] = s;
+    }
+    uint32_t e = 0;
+    for (int i = tid; i < htiles; i += 256) e += tile_count[(int64_t)frame * htiles + i];
+    double fs = 0.0, fs2 = 0.0;
+    for (int i = tid; i < nfparts; i += 256) {
+        const double2 p = fpart[(int64_t)frame * nfparts + i];
+        fs += p.x;
+        fs2 += p.y;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o, 64);
+        fs += __shfl_xor(fs, o, 64);
+        fs2 += __shfl_xor(fs2, o, 64);
+    }
+    if ((tid & 63) == 0) { ered[tid >> 6] = e; dred[0][tid >> 6] = fs; dred[1][tid >> 6] = fs2; }
     __syncthreads();
-    if (threadIdx.x == 0) acc[frame].edge_count = part[0] + part[1] + part[2] + part[3];
+    FrameAcc* fa = acc + frame;
+    if (tid < 14) {
+        unsigned long long s = 0;
+        for (int i = 0; i < 16; ++i) s += red[tid][i];
+        if (tid < 10) {
+            if (lbp_from_tiles) fa->lbp_hist[tid] = (uint32_t)s;
+        } else if (tid == 10) fa->hp_sum = s;
+        else if (tid == 11) fa->hp_sumsq = s;
+        else if (tid == 12) fa->absdiff_sum = s;
+        else fa->gray_sum = s;
+    }
+    if (tid == 64) {
+        fa->edge_count = ered[0] + ered[1] + ered[2] + ered[3];
+        fa->fft_sum = ((dred[0][0] + dred[0][1]) + dred[0][2]) + dred[0][3];
+        fa->fft_sumsq = ((dred[1][0] + dred[1][1]) + dred[1][2]) + dred[1][3];
+    }
 }
 
 __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long long* __restrict__ strong, int H, int W,
@@ -118,8 +158,10 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
                        tile_count);
 }
 
-void launch_edge_count(hipStream_t s, const uint32_t* tile_count, int n_frames, const Geom& g, FrameAcc* acc) {
-    hipLaunchKernelGGL(edge_count_kernel, dim3(n_frames), dim3(256), 0, s, tile_count, g.htiles_y * g.wpr, acc);
+void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
+                         const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc) {
+    hipLaunchKernelGGL(frame_reduce_kernel, dim3(n_frames), dim3(256), 0, s, spart, g.tiles_x * g.tiles_y,
+                       lbp_from_tiles ? 1 : 0, tile_count, g.htiles_y * g.wpr, fpart, nfparts, acc);
 }
 
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges) {

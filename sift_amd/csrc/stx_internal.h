@@ -54,10 +54,10 @@ struct FftPlan {
 
 // ---- launchers (each file owns its kernels) ----
 void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
-                 const Geom& g, int shift, uint8_t* gray, FrameAcc* acc);
+                 const Geom& g, int shift, uint8_t* gray);
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
-                    const LbpOffsets& off, int low, int high, FrameAcc* acc, unsigned long long* strong,
+                    const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out);
 
 void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
@@ -67,7 +67,8 @@ void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
 // changed nothing.  changed[] must be zeroed before pass 0.
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count);
-void launch_edge_count(hipStream_t s, const uint32_t* tile_count, int n_frames, const Geom& g, FrameAcc* acc);
+void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
+                         const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);
 
 // Real 2-D FFT of the (cropped) gray plane minus 128, log-magnitude statistics.
@@ -83,7 +84,6 @@ void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
                      const FftPlan& plan, const float2* tw, float2* spec);
 void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
                      const FftPlan& plan, const float2* tw, double2* part);
-void launch_fft_reduce(hipStream_t s, const double2* part, int n_frames, int parts_per_frame, FrameAcc* acc);
 // compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
 bool fft_fast_available(int n);
 int fft_fast_stride(int n);

@@ -53,7 +53,7 @@ struct StencilArgs {
     int H, W, gpitch, grows, wpr;
     int low, high;
     double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
-    FrameAcc* acc;
+    uint32_t* part;  // [frame][tiles][16]: 10 LBP bins, hp sum, hp sum of squares, |gray-blur| sum, gray sum
     unsigned long long* strong;
     unsigned long long* cand;
     uint8_t* codes;  // optional per-pixel LBP codes [frame][H][W]
@@ -144,7 +144,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     }
 
     unsigned long long hist6 = 0;  // ten 6-bit counters
-    uint32_t hp_s = 0, hp_q = 0, ad_s = 0;
+    uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 #pragma unroll
             for (int r = 1; r <= 3; ++r) s9 += g[r][1] + g[r][2] + g[r][3];
             const int v = iclamp(9 * c - s9, 0, 255);
-            if (valid) { hp_s += v; hp_q += v * v; }
+            if (valid) { hp_s += v; hp_q += v * v; gr_s += c; }
         }
         // ---- Gaussian residual
         {
@@ -266,6 +266,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     hp_s = wave_sum_u32(hp_s);
     hp_q = wave_sum_u32(hp_q);
     ad_s = wave_sum_u32(ad_s);
+    gr_s = wave_sum_u32(gr_s);
     if (lane == 0) {
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
@@ -275,6 +276,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         red[10] = hp_s;
         red[11] = hp_q;
         red[12] = ad_s;
+        red[13] = gr_s;
     }
 }
 
@@ -305,20 +307,16 @@ __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
     else
         march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
     __syncthreads();
-    if (tid < 13) {
-        const uint32_t v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        FrameAcc* fa = a.acc + frame;
-        if (tid < 10) {
-            if (DO_LBP && v) atomicAdd(&fa->lbp_hist[tid], v);
-        } else if (v) {
-            unsigned long long* dst = tid == 10 ? &fa->hp_sum : (tid == 11 ? &fa->hp_sumsq : &fa->absdiff_sum);
-            atomicAdd(dst, (unsigned long long)v);
-        }
+    // per-tile partial sums, one slot per tile: no atomics, summed in a fixed order later
+    if (tid < 16) {
+        const uint32_t v = tid < 14 ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0u;
+        const int64_t tile = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.part[tile * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
     }
 }
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
-                    const LbpOffsets& off, int low, int high, FrameAcc* acc, unsigned long long* strong,
+                    const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out) {
     StencilArgs a;
     a.gray = gray;
@@ -326,7 +324,7 @@ void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom
     a.low = low; a.high = high;
     // (P=8,R=1): samples 1,3 sit above the centre (rp<0), 5,7 below; 1,7 right (cp>0), 3,5 left
     a.rp_neg = off.rp[1]; a.rp_pos = off.rp[5]; a.cp_pos = off.cp[1]; a.cp_neg = off.cp[3];
-    a.acc = acc; a.strong = strong; a.cand = cand; a.codes = codes_out;
+    a.part = part; a.strong = strong; a.cand = cand; a.codes = codes_out;
     dim3 grid(g.tiles_x, g.tiles_y, n_frames);
     if (!do_lbp81)
         hipLaunchKernelGGL((stencil_kernel<false, false>), grid, dim3(256), 0, s, a);
