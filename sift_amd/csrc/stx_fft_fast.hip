@@ -164,18 +164,28 @@ struct Dft<5> {
 
 // ---------------------------------------------------------------- plans
 // N = R0*R1*R2*R3 (unused radices are 1); LPT = lanes per transform (16, 32 or 64)
+// LDS bank conflicts: reads of a pass are 32 consecutive elements per half wave and never
+// conflict; the writes of the FIRST pass are strided by R0 elements.  An odd R0 makes that
+// stride hit all banks, so every size with an odd factor starts with one.  Powers of two use an
+// XOR swizzle of the low four index bits by the next four instead (it permutes elements inside
+// aligned 16-element groups, which keeps the aligned reads conflict-free).
 template <int N_, int R0_, int R1_, int R2_, int R3_, int LPT_>
 struct Plan {
     static constexpr int N = N_, R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_, LPT = LPT_;
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
-    static constexpr int TPW = 64 / LPT_;                    // transforms per wave
-    static constexpr int S = (N_ + (N_ >> 4) + 1) | 1;      // LDS elements per transform (padded, odd)
+    static constexpr int TPW = 64 / LPT_;          // transforms per wave
+    static constexpr int S = N_ | 1;               // LDS elements per transform (odd: see cols_kernel)
+    static constexpr bool SWZ = (N_ & (N_ - 1)) == 0;
+    static_assert(SWZ || (R0_ & 1), "sizes with an odd factor must start with an odd radix");
 };
 
-__device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+template <bool SWZ>
+__device__ __forceinline__ int pad(int i) {
+    return SWZ ? (i ^ ((i >> 4) & 15)) : i;
+}
 
 // One Stockham pass of radix R; NS = product of the radices already applied.
-template <int N, int R, int NS, int LPT>
+template <int N, int R, int NS, int LPT, bool SWZ>
 __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t) {
     if constexpr (R > 1) {
         constexpr int M = N / R;
@@ -186,7 +196,7 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
             const int j = t + it * LPT;
             if (ITER * LPT == M || j < M) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) v[it][r] = buf[pad(j + r * M)];
+                for (int r = 0; r < R; ++r) v[it][r] = buf[pad<SWZ>(j + r * M)];
             }
         }
 #pragma unroll
@@ -206,7 +216,7 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
                 Dft<R>::run(v[it]);
                 const int o = (j - k) * R + k;
 #pragma unroll
-                for (int r = 0; r < R; ++r) buf[pad(o + r * NS)] = v[it][r];
+                for (int r = 0; r < R; ++r) buf[pad<SWZ>(o + r * NS)] = v[it][r];
             }
         }
     }
@@ -214,10 +224,10 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
 
 template <class P>
 __device__ __forceinline__ void transform(float2* buf, const float2* twg, int t) {
-    pass<P::N, P::R0, 1, P::LPT>(buf, twg, t);
-    pass<P::N, P::R1, P::R0, P::LPT>(buf, twg, t);
-    pass<P::N, P::R2, P::R0 * P::R1, P::LPT>(buf, twg, t);
-    pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT>(buf, twg, t);
+    pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, twg, t);
+    pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t);
+    pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t);
+    pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t);
 }
 
 // ---------------------------------------------------------------- kernels
@@ -250,12 +260,12 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
             const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : 0x80808080u;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                buf[pad(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
+                buf[pad<P::SWZ>(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
                                                    (float)((int)((wb >> (8 * q)) & 255u) - 128));
         }
     } else {
         for (int x = t; x < N; x += LPT)
-            buf[pad(x)] = make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
+            buf[pad<P::SWZ>(x)] = make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
     }
     transform<P>(buf, a.tw, t);
     if (!ina) return;
@@ -263,8 +273,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     const int cbw = a.cbw;
     float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw;
     for (int k = t; k <= N / 2; k += LPT) {
-        const float2 zk = buf[pad(k)];
-        const float2 zc = buf[pad(k ? N - k : 0)];
+        const float2 zk = buf[pad<P::SWZ>(k)];
+        const float2 zc = buf[pad<P::SWZ>(k ? N - k : 0)];
         const int kb = k / cbw, kc = k - kb * cbw;
         float2* o = base + ((int64_t)kb * a.fh + ra) * cbw + kc;
         o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
@@ -296,11 +306,11 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
         for (int e = tid; e < N * half; e += nthreads) {
             const float4 q = src4[e];
             const int y = e / half, c = 2 * (e - y * half);
-            dynlds[c * S + pad(y)] = make_float2(q.x, q.y);
-            dynlds[(c + 1) * S + pad(y)] = make_float2(q.z, q.w);
+            dynlds[c * S + pad<P::SWZ>(y)] = make_float2(q.x, q.y);
+            dynlds[(c + 1) * S + pad<P::SWZ>(y)] = make_float2(q.z, q.w);
         }
     } else {
-        for (int y = tid; y < N; y += nthreads) dynlds[pad(y)] = src[y];
+        for (int y = tid; y < N; y += nthreads) dynlds[pad<P::SWZ>(y)] = src[y];
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     if (k < a.fwh) {
         const float dc_fix = 128.0f * (float)N * (float)a.fw;
         for (int y = t; y < N; y += LPT) {
-            float2 v = buf[pad(y)];
+            float2 v = buf[pad<P::SWZ>(y)];
             if (k == 0 && y == 0) v.x += dc_fix;
             const float mag = sqrtf(v.x * v.x + v.y * v.y);
             const double l = (double)logf(mag + 1.0f);
@@ -334,28 +344,28 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
 }
 
 // ---------------------------------------------------------------- size table
-#define STX_FFT_SIZES(X)      \
-    X(64, 8, 8, 1, 1, 16)     \
-    X(80, 10, 8, 1, 1, 16)    \
-    X(96, 12, 8, 1, 1, 16)    \
-    X(128, 16, 8, 1, 1, 16)   \
-    X(160, 16, 10, 1, 1, 16)  \
-    X(240, 16, 15, 1, 1, 16)  \
-    X(256, 16, 16, 1, 1, 16)  \
-    X(320, 8, 8, 5, 1, 64)    \
-    X(360, 9, 8, 5, 1, 64)    \
-    X(480, 10, 8, 6, 1, 64)   \
-    X(512, 8, 8, 8, 1, 64)    \
-    X(540, 10, 9, 6, 1, 64)   \
-    X(640, 10, 8, 8, 1, 64)   \
-    X(720, 10, 9, 8, 1, 64)   \
-    X(768, 12, 8, 8, 1, 64)   \
-    X(960, 12, 10, 8, 1, 64)  \
-    X(1024, 16, 8, 8, 1, 64)  \
-    X(1080, 12, 10, 9, 1, 64) \
-    X(1280, 16, 10, 8, 1, 64) \
-    X(1440, 12, 12, 10, 1, 64) \
-    X(1920, 16, 12, 10, 1, 64) \
+#define STX_FFT_SIZES(X)       \
+    X(64, 8, 8, 1, 1, 16)      \
+    X(80, 5, 16, 1, 1, 16)     \
+    X(96, 3, 8, 4, 1, 32)      \
+    X(128, 16, 8, 1, 1, 16)    \
+    X(160, 5, 8, 4, 1, 32)     \
+    X(240, 15, 16, 1, 1, 16)   \
+    X(256, 16, 16, 1, 1, 16)   \
+    X(320, 5, 8, 8, 1, 64)     \
+    X(360, 9, 8, 5, 1, 64)     \
+    X(480, 15, 8, 4, 1, 64)    \
+    X(512, 8, 8, 8, 1, 64)     \
+    X(540, 9, 10, 6, 1, 64)    \
+    X(640, 5, 16, 8, 1, 64)    \
+    X(720, 9, 10, 8, 1, 64)    \
+    X(768, 3, 16, 16, 1, 64)   \
+    X(960, 15, 8, 8, 1, 64)    \
+    X(1024, 16, 8, 8, 1, 64)   \
+    X(1080, 9, 12, 10, 1, 64)  \
+    X(1280, 5, 16, 16, 1, 64)  \
+    X(1440, 9, 16, 10, 1, 64)  \
+    X(1920, 15, 16, 8, 1, 64)  \
     X(2048, 16, 16, 8, 1, 64)
 
 template <class P>

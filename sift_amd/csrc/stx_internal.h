@@ -28,7 +28,7 @@ struct Geom {
     int grows;       // rows of the padded gray plane: H+4 (two reflected rows above and below)
     int wpr;         // 64-pixel bitmap words per row: ceil(W/64)
     int tiles_x;     // ceil(W/64)
-    int tiles_y;     // ceil(H/32) stencil tiles
+    int tiles_y;     // ceil(H/128) stencil tiles
     int htiles_y;    // ceil(H/64) hysteresis tiles
     int fh, fw;      // FFT extent
     int foy, fox;    // FFT crop origin in the frame

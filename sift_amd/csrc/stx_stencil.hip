@@ -4,13 +4,15 @@
 //   * 5x5 Gaussian residual |gray - blur| -> sum             (:111-113)
 //   * Sobel + L1 magnitude + non-maximum suppression + double threshold
 //     -> two bitmaps (strong, candidate), one bit per pixel  (:116, first half of Canny)
-// A 256-thread workgroup owns a 64x32 pixel tile; each wave owns 8 rows, each lane one
+// A 256-thread workgroup owns a 64x128 pixel tile; each wave owns 32 rows, each lane one
 // column, and marches down its column with the 5x5 neighbourhood held in registers.  The
 // wave's 64 lanes are 64 consecutive pixels, so __ballot() of a per-pixel predicate IS the
 // 64-bit bitmap word of that row.
 //
-// LBP arithmetic is fp64 with every operation rounded separately in the order scikit-image
-// performs it; this file must be compiled with -ffp-contract=off.
+// LBP bits are those of the fp64 arithmetic scikit-image performs (every operation rounded
+// separately, in its order); an fp32 evaluation with a proven error margin settles the clear
+// cases and only near-ties run the fp64 sequence.  This file must be compiled with
+// -ffp-contract=off.
 #include "stx_internal.h"
 
 namespace stx {
@@ -18,8 +20,10 @@ namespace stx {
 #pragma clang fp contract(off)
 
 constexpr int TILE_W = 64;
-constexpr int TILE_H = 32;
-constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+33
+constexpr int WAVE_ROWS = 32;       // rows marched by one wave
+constexpr int BLOCK_ROWS = 8;       // rows per unrolled block
+constexpr int TILE_H = 4 * WAVE_ROWS;
+constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+TILE_H+1
 constexpr int LPITCH = 72;         // bytes: columns x0-4 .. x0+67
 constexpr int LDW = LPITCH / 4;
 
@@ -64,7 +68,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                                       int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
     const int x = x0 + lane;
-    const int ys = y0 + wv * 8;
+    const int ys = y0 + wv * WAVE_ROWS;
     const int lc = lane + GRAY_XOFF;  // LDS column of pixel x
     const bool xin = x < W;
 
@@ -81,6 +85,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         const double cfn = (double)x + a.cp_neg;
         dcN = cfn - floor(cfn);
     }
+    const float wcP = (float)dcP, wcN = (float)dcN;
 
     // sliding state
     int g[5][5];   // reflected view, rows y-2..y+2, cols x-2..x+2
@@ -91,7 +96,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     int dxc[2], dyc[2];  // gradient at (y,x) and (y+1,x)
 
     auto load_row = [&](int r, int (&gr)[5], int& hsum, int (&d)[3], int (&s)[3]) {
-        // r: global row index in [y0-2, y0+33]
+        // r: global row index in [y0-2, y0+TILE_H+1]
         const uint8_t* rowp = tile + (r - y0 + 2) * LPITCH;
 #pragma unroll
         for (int j = 0; j < 5; ++j) gr[j] = rowp[lc + j - 2];
@@ -128,133 +133,186 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             if (j == 1) { gx = ddx; gy = ddy; }
         }
     };
+    // zero-padded pixel for the LBP fix-up (any row/column of the tile, dynamic indices)
+    auto lbp_px = [&](int yy, int xx) -> double {
+        if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
+        return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+    };
 
     // prologue: rows ys-2 .. ys+1
     int dtmp[3], stmp[3];
-    load_row(ys - 2, g[0], hg[0], dtmp, stmp);           // Sobel never needs row ys-2
+    load_row(ys - 2, g[0], hg[0], dtmp, stmp);
     int dm1[3], sm1[3];
     load_row(ys - 1, g[1], hg[1], dm1, sm1);
     load_row(ys, g[2], hg[2], sd[0], ss[0]);
     load_row(ys + 1, g[3], hg[3], sd[1], ss[1]);
     {
-        // magnitude row ys-1 needs row ys-2 in the Canny view
         int gx, gy;
         sobel_row(ys - 1, dtmp, dm1, sd[0], stmp, ss[0], mag[0], gx, gy);
         sobel_row(ys, dm1, sd[0], sd[1], sm1, ss[1], mag[1], dxc[0], dyc[0]);
     }
 
-    unsigned long long hist6 = 0;  // ten 6-bit counters
+    unsigned long long hist6 = 0;  // ten 6-bit counters (at most 32 pixels per lane)
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
 
+#pragma unroll 1
+    for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
+        const int yb = ys + blk * BLOCK_ROWS;
+        if (yb >= H) break;  // wave-uniform: nothing left in the image
+        unsigned long long bits64 = 0;  // 8 LBP bits per row of this block
+        uint32_t pend = 0;              // bit 4*row+k: diagonal sample k of that row needs the fp64 evaluation
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int y = ys + i;
-        load_row(y + 2, g[4], hg[4], sd[2], ss[2]);
-        sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
-        const bool valid = xin && (y < H);
-        const int c = g[2][2];
+        for (int i = 0; i < BLOCK_ROWS; ++i) {
+            const int y = yb + i;
+            load_row(y + 2, g[4], hg[4], sd[2], ss[2]);
+            sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
+            const bool valid = xin && (y < H);
+            const int c = g[2][2];
 
-        // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
-        {
-            int s9 = 0;
+            // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
+            {
+                int s9 = 0;
 #pragma unroll
-            for (int r = 1; r <= 3; ++r) s9 += g[r][1] + g[r][2] + g[r][3];
-            const int v = iclamp(9 * c - s9, 0, 255);
-            if (valid) { hp_s += v; hp_q += v * v; gr_s += c; }
-        }
-        // ---- Gaussian residual
-        {
-            const int S = hg[0] + hg[4] + 4 * (hg[1] + hg[3]) + 6 * hg[2];
-            const int blur = (S + 128) >> 8;
-            if (valid) ad_s += abs(c - blur);
-        }
-        // ---- LBP (P=8, R=1)
-        if (DO_LBP) {
-            double n[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    int v = g[r + 1][q + 1];
-                    if (BORDER) {
-                        const int yy = y + r - 1, xx = x + q - 1;
-                        if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
-                    }
-                    n[r][q] = (double)v;
-                }
-            const double rfn = (double)y + a.rp_neg;  // samples above the centre
-            const double drN = rfn - floor(rfn);
-            const double rfp = (double)y + a.rp_pos;  // samples below
-            const double drP = rfp - floor(rfp);
-            const double ce = n[1][1];
-            uint32_t bits = 0;
-            bits |= (n[1][2] - ce >= 0.0) ? 1u : 0u;                                        // (0,+1)
-            bits |= lbp_bit(n[0][1], n[0][2], n[1][1], n[1][2], drN, dcP, ce) << 1;          // (-.7,+.7)
-            bits |= ((n[0][1] - ce >= 0.0) ? 1u : 0u) << 2;                                  // (-1,0)
-            bits |= lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce) << 3;          // (-.7,-.7)
-            bits |= ((n[1][0] - ce >= 0.0) ? 1u : 0u) << 4;                                  // (0,-1)
-            bits |= lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce) << 5;          // (+.7,-.7)
-            bits |= ((n[2][1] - ce >= 0.0) ? 1u : 0u) << 6;                                  // (+1,0)
-            bits |= lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce) << 7;          // (+.7,+.7)
-            const int changes = __popc((bits ^ (bits >> 1)) & 0x7Fu);
-            const int code = (changes <= 2) ? __popc(bits) : 9;
-            if (valid) {
-                hist6 += 1ull << (6 * code);
-                if (CODES) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)code;
+                for (int r = 1; r <= 3; ++r) s9 += g[r][1] + g[r][2] + g[r][3];
+                const int v = iclamp(9 * c - s9, 0, 255);
+                if (valid) { hp_s += v; hp_q += v * v; gr_s += c; }
             }
-        }
-        // ---- Canny non-maximum suppression + double threshold
-        {
-            const int m = mag[1][1];
-            int cls = 0;
-            if (m > a.low) {
-                const int xs = dxc[0], ysg = dyc[0];
-                const int ax = abs(xs), ay = abs(ysg) << 15;
-                const int tg22x = ax * 13573;
-                bool keep;
-                if (ay < tg22x) {
-                    keep = (m > mag[1][0]) && (m >= mag[1][2]);
-                } else {
-                    const int tg67x = tg22x + (ax << 16);
-                    if (ay > tg67x) {
-                        keep = (m > mag[0][1]) && (m >= mag[2][1]);
-                    } else if ((xs ^ ysg) < 0) {
-                        keep = (m > mag[0][2]) && (m > mag[2][0]);
+            // ---- Gaussian residual
+            {
+                const int S = hg[0] + hg[4] + 4 * (hg[1] + hg[3]) + 6 * hg[2];
+                const int blur = (S + 128) >> 8;
+                if (valid) ad_s += abs(c - blur);
+            }
+            // ---- LBP (P=8, R=1), first stage
+            if (DO_LBP) {
+                int n[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        int v = g[r + 1][q + 1];
+                        if (BORDER) {
+                            const int yy = y + r - 1, xx = x + q - 1;
+                            if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
+                        }
+                        n[r][q] = v;
+                    }
+                // rows are wave-uniform: the weights cost a handful of fp64 operations per row
+                const double rfn = (double)y + a.rp_neg;
+                const float wrN = (float)(rfn - floor(rfn));
+                const double rfp = (double)y + a.rp_pos;
+                const float wrP = (float)(rfp - floor(rfp));
+                const int ce = n[1][1];
+                // The four axis samples have integer coordinates: the interpolation returns the pixel
+                // itself, so the comparison is an integer one.
+                uint32_t bits = (n[1][2] >= ce ? 1u : 0u) | (n[0][1] >= ce ? 4u : 0u) | (n[1][0] >= ce ? 16u : 0u) |
+                                (n[2][1] >= ce ? 64u : 0u);
+                // Diagonal samples in fp32: its value is within 2e-4 of the exact bilinear value and the
+                // fp64 sequence within 1e-12, so |value - centre| >= 1e-3 settles the sign; anything
+                // closer is queued for the order-exact fp64 evaluation after this block.
+                uint32_t unc = 0;
+                auto diag = [&](int tl, int tr, int bl, int br, float wr, float wc, int k) {
+                    const float top = __builtin_fmaf(wc, (float)(tr - tl), (float)tl);
+                    const float bot = __builtin_fmaf(wc, (float)(br - bl), (float)bl);
+                    const float d = __builtin_fmaf(wr, bot - top, top) - (float)ce;
+                    bits |= (d >= 0.f ? 1u : 0u) << (2 * k + 1);
+                    unc |= (__builtin_fabsf(d) < 1e-3f ? 1u : 0u) << k;
+                };
+                diag(n[0][1], n[0][2], n[1][1], n[1][2], wrN, wcP, 0);  // sample 1 (-.7,+.7)
+                diag(n[0][0], n[0][1], n[1][0], n[1][1], wrN, wcN, 1);  // sample 3 (-.7,-.7)
+                diag(n[1][0], n[1][1], n[2][0], n[2][1], wrP, wcN, 2);  // sample 5 (+.7,-.7)
+                diag(n[1][1], n[1][2], n[2][1], n[2][2], wrP, wcP, 3);  // sample 7 (+.7,+.7)
+                if (valid) {
+                    bits64 |= (unsigned long long)bits << (8 * i);
+                    pend |= unc << (4 * i);
+                }
+            }
+            // ---- Canny non-maximum suppression + double threshold
+            {
+                const int m = mag[1][1];
+                int cls = 0;
+                if (m > a.low) {
+                    const int xs = dxc[0], ysg = dyc[0];
+                    const int ax = abs(xs), ay = abs(ysg) << 15;
+                    const int tg22x = ax * 13573;
+                    bool keep;
+                    if (ay < tg22x) {
+                        keep = (m > mag[1][0]) && (m >= mag[1][2]);
                     } else {
-                        keep = (m > mag[0][0]) && (m > mag[2][2]);
+                        const int tg67x = tg22x + (ax << 16);
+                        if (ay > tg67x) {
+                            keep = (m > mag[0][1]) && (m >= mag[2][1]);
+                        } else if ((xs ^ ysg) < 0) {
+                            keep = (m > mag[0][2]) && (m > mag[2][0]);
+                        } else {
+                            keep = (m > mag[0][0]) && (m > mag[2][2]);
+                        }
                     }
+                    if (keep) cls = (m > a.high) ? 2 : 1;
                 }
-                if (keep) cls = (m > a.high) ? 2 : 1;
+                if (!valid) cls = 0;
+                const unsigned long long sb = __ballot(cls == 2);
+                const unsigned long long cb = __ballot(cls >= 1);
+                if (lane == 0 && y < H) {
+                    const int64_t wi = ((int64_t)frame * H + y) * a.wpr + (x0 >> 6);
+                    a.strong[wi] = sb;
+                    a.cand[wi] = cb;
+                }
             }
-            if (!valid) cls = 0;
-            const unsigned long long sb = __ballot(cls == 2);
-            const unsigned long long cb = __ballot(cls >= 1);
-            if (lane == 0 && y < H) {
-                const int64_t wi = ((int64_t)frame * H + y) * a.wpr + (x0 >> 6);
-                a.strong[wi] = sb;
-                a.cand[wi] = cb;
+            // ---- slide down one row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) g[r][j] = g[r + 1][j];
+                hg[r] = hg[r + 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    sd[r][j] = sd[r + 1][j];
+                    ss[r][j] = ss[r + 1][j];
+                    mag[r][j] = mag[r + 1][j];
+                }
+            dxc[0] = dxc[1];
+            dyc[0] = dyc[1];
+        }
+        if (DO_LBP) {
+            // ---- LBP second stage: near-ties, one (row, sample) per lane and iteration, in the fp64
+            // arithmetic of skimage's bilinear_interpolation (operands re-read from the LDS tile)
+            while (__any(pend != 0)) {
+                if (pend != 0) {
+                    const int b = __ffs(pend) - 1;
+                    pend &= pend - 1;
+                    const int i = b >> 2, k = b & 3;
+                    const int y = yb + i;
+                    const int r0 = (k >= 2) ? y : y - 1;             // upper row of the 2x2 cell
+                    const int c0 = (k == 1 || k == 2) ? x - 1 : x;  // left column of the cell
+                    const double rf = (double)y + ((k >= 2) ? a.rp_pos : a.rp_neg);
+                    const double dr = rf - floor(rf);
+                    const double dc = (k == 1 || k == 2) ? dcN : dcP;
+                    const uint32_t bit = lbp_bit(lbp_px(r0, c0), lbp_px(r0, c0 + 1), lbp_px(r0 + 1, c0),
+                                                 lbp_px(r0 + 1, c0 + 1), dr, dc, lbp_px(y, x));
+                    const int pos = 8 * i + 2 * k + 1;
+                    bits64 = (bits64 & ~(1ull << pos)) | ((unsigned long long)bit << pos);
+                }
+            }
+            // ---- codes and histogram of this block
+#pragma unroll
+            for (int i = 0; i < BLOCK_ROWS; ++i) {
+                const int y = yb + i;
+                const uint32_t bits = (uint32_t)(bits64 >> (8 * i)) & 0xFFu;
+                const int changes = __popc((bits ^ (bits >> 1)) & 0x7Fu);
+                const int code = (changes <= 2) ? __popc(bits) : 9;
+                if (xin && y < H) {
+                    hist6 += 1ull << (6 * code);
+                    if (CODES) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)code;
+                }
             }
         }
-        // ---- slide down one row
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) g[r][j] = g[r + 1][j];
-            hg[r] = hg[r + 1];
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                sd[r][j] = sd[r + 1][j];
-                ss[r][j] = ss[r + 1][j];
-                mag[r][j] = mag[r + 1][j];
-            }
-        dxc[0] = dxc[1];
-        dyc[0] = dyc[1];
     }
 
-    // ---- wave reduction: 10 histogram bins (two words of five 12-bit fields), three sums
+    // ---- wave reduction: 10 histogram bins (two words of five 12-bit fields), four sums
     unsigned long long lo = 0, hi = 0;
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
@@ -297,21 +355,25 @@ __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
         gy = gy < a.grows ? gy : a.grows - 1;
         tile[i] = *reinterpret_cast<const uint32_t*>(gp + (int64_t)gy * a.gpitch + x0 + col * 4);
     }
+    if (tid < 64) red[tid >> 4][tid & 15] = 0;
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
-    // interior: the tile and its two-pixel halo lie inside the image
-    const bool interior = (x0 >= 2) && (y0 >= 2) && (x0 + TILE_W + 2 <= a.W) && (y0 + TILE_H + 2 <= a.H);
-    if (interior)
-        march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
-    else
-        march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+    const int ys = y0 + wv * WAVE_ROWS;
+    if (ys < a.H) {
+        // interior: the wave's strip and its two-pixel halo lie inside the image
+        const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
+        if (interior)
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+        else
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+    }
     __syncthreads();
     // per-tile partial sums, one slot per tile: no atomics, summed in a fixed order later
     if (tid < 16) {
         const uint32_t v = tid < 14 ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0u;
-        const int64_t tile = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.part[tile * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
+        const int64_t tileid = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.part[tileid * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
     }
 }
 
