@@ -37,7 +37,7 @@ struct TimedSpan {
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
-    DevBuf gray, strong, cand, spec, part, tiles, spart, acc, changed, staging;
+    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, acc, changed, staging;
     FrameAcc* acc_host = nullptr;  // pinned
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
@@ -290,7 +290,7 @@ int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g) {
     Span sp(c, &sl.spans, STX_K_HYST, n);
     for (int i = 0; i < n; ++i, ++sl.passes)
         launch_hyst_pass(c->stream, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
-                         (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p);
+                         (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
     sp.end();
     return STX_OK;
 }
@@ -327,6 +327,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     if ((rc = ensure(c, sl.spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.tflag, (size_t)2 * F * g.htiles_y * g.wpr)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.spart, (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
@@ -481,7 +482,7 @@ int stx_destroy(stx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Slot& sl : c->slot) {
-        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);

@@ -271,6 +271,7 @@ FftLayout fft_choose_layout(const Geom& g) {
         cbw = FFT_LDS_MAX / (2 * g.fh * (int)sizeof(float2));
         if (cbw > 8) cbw = 8;
         if (cbw < 1) cbw = 1;
+        while (cbw & (cbw - 1)) cbw &= cbw - 1;  // the block width is always a power of two
     }
     l.cbw = cbw;
     l.nkb = (g.fwh + cbw - 1) / cbw;

@@ -235,7 +235,8 @@ struct RowsArgs {
     const uint8_t* gray;
     int gpitch, grows;
     int foy, fox, fh, fwh;
-    int cbw, nkb;  // column-block width and count of the spectrum layout
+    int cbw, nkb;  // column-block width (a power of two) and count of the spectrum layout
+    int cbw_log2;
     const float2* tw;
     float2* spec;
 };
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     for (int k = t; k <= N / 2; k += LPT) {
         const float2 zk = buf[pad<P::SWZ>(k)];
         const float2 zc = buf[pad<P::SWZ>(k ? N - k : 0)];
-        const int kb = k / cbw, kc = k - kb * cbw;
-        float2* o = base + ((int64_t)kb * a.fh + ra) * cbw + kc;
+        const int kb = k >> a.cbw_log2, kc = k & (cbw - 1);
+        float2* o = base + (((int64_t)kb * a.fh + ra) << a.cbw_log2) + kc;
         o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
         if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
     }
@@ -286,6 +287,7 @@ struct ColsArgs {
     const float2* spec;
     int fw, fwh;
     int cbw, nkb;
+    int cbw_log2;
     const float2* tw;
     double2* part;  // [frame][nkb*cbw]
 };
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
         const int half = cbw >> 1;
         for (int e = tid; e < N * half; e += nthreads) {
             const float4 q = src4[e];
-            const int y = e / half, c = 2 * (e - y * half);
+            const int y = e >> (a.cbw_log2 - 1), c = 2 * (e & (half - 1));
             dynlds[c * S + pad<P::SWZ>(y)] = make_float2(q.x, q.y);
             dynlds[(c + 1) * S + pad<P::SWZ>(y)] = make_float2(q.z, q.w);
         }
@@ -443,7 +445,7 @@ bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, cons
     RowsArgs a;
     a.gray = gray; a.gpitch = g.gpitch; a.grows = g.grows;
     a.foy = g.foy; a.fox = g.fox; a.fh = g.fh; a.fwh = g.fwh;
-    a.cbw = lay.cbw; a.nkb = lay.nkb; a.tw = tw; a.spec = spec;
+    a.cbw = lay.cbw; a.nkb = lay.nkb; a.cbw_log2 = __builtin_ctz(lay.cbw); a.tw = tw; a.spec = spec;
     switch (g.fw) {
 #define X(N, A, B, C, D, L)                                    \
     case N:                                                    \
@@ -459,7 +461,8 @@ bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, cons
 bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
                           const float2* tw, double2* part) {
     ColsArgs a;
-    a.spec = spec; a.fw = g.fw; a.fwh = g.fwh; a.cbw = lay.cbw; a.nkb = lay.nkb; a.tw = tw; a.part = part;
+    a.spec = spec; a.fw = g.fw; a.fwh = g.fwh; a.cbw = lay.cbw; a.nkb = lay.nkb; a.cbw_log2 = __builtin_ctz(lay.cbw);
+    a.tw = tw; a.part = part;
     switch (g.fh) {
 #define X(N, A, B, C, D, L)                                    \
     case N:                                                    \

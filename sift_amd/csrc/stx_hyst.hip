@@ -25,13 +25,32 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
     return up | dn | x;
 }
 
+// tflag: [2][frames][htiles_y][wpr] bytes, one per tile and pass parity: "this tile changed in
+// that pass".  From pass 1 on a tile is revisited only if it or one of its eight neighbours
+// changed in the previous pass.
 __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
                                                        const unsigned long long* __restrict__ cand, int H, int wpr,
                                                        int htiles_y, unsigned int* changed, int pass,
-                                                       uint32_t* __restrict__ tile_count) {
+                                                       uint32_t* __restrict__ tile_count, uint8_t* tflag,
+                                                       int64_t tflag_half) {
     if (pass > 0 && changed[pass - 1] == 0) return;
     const int frame = blockIdx.z, ty = blockIdx.y, wx = blockIdx.x;
     const int lane = threadIdx.x;
+    const int64_t tbase = (int64_t)frame * htiles_y * wpr;
+    uint8_t* fl_cur = tflag + (int64_t)(pass & 1) * tflag_half + tbase;
+    if (pass > 0) {
+        const uint8_t* fl_prev = tflag + (int64_t)((pass - 1) & 1) * tflag_half + tbase;
+        // lanes 0..8 look at the 3x3 tile neighbourhood
+        int f = 0;
+        if (lane < 9) {
+            const int ny = ty + lane / 3 - 1, nx = wx + lane % 3 - 1;
+            if (ny >= 0 && ny < htiles_y && nx >= 0 && nx < wpr) f = fl_prev[ny * wpr + nx];
+        }
+        if (!__any(f != 0)) {
+            if (lane == 0) fl_cur[ty * wpr + wx] = 0;
+            return;
+        }
+    }
     const int y = ty * 64 + lane;
     unsigned long long* sb = strong + (int64_t)frame * H * wpr;
     const unsigned long long* cb = cand + (int64_t)frame * H * wpr;
@@ -83,12 +102,16 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
 
     const bool ch = S != orig;
     if (ch) sb[(int64_t)y * wpr + wx] = S;
-    // a flag, not a count: every writer stores the same value, so a plain store is enough
-    if (__any(ch) && lane == 0) changed[pass] = 1u;
+    const bool tile_changed = __any(ch);
     uint32_t cnt = __popcll(S);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) tile_count[((int64_t)frame * htiles_y + ty) * wpr + wx] = cnt;
+    if (lane == 0) {
+        // a flag, not a count: every writer stores the same value, so a plain store is enough
+        if (tile_changed) changed[pass] = 1u;
+        fl_cur[ty * wpr + wx] = tile_changed ? 1 : 0;
+        tile_count[tbase + ty * wpr + wx] = cnt;
+    }
 }
 
 // Per-frame reduction of everything the other kernels left as partials, in a fixed order
@@ -152,10 +175,11 @@ __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long l
 }
 
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count) {
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
     dim3 grid(g.wpr, g.htiles_y, n_frames);
+    const int64_t half = (int64_t)n_frames * g.htiles_y * g.wpr;
     hipLaunchKernelGGL(hyst_pass_kernel, grid, dim3(64), 0, s, strong, cand, g.H, g.wpr, g.htiles_y, changed, pass,
-                       tile_count);
+                       tile_count, tflag, half);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

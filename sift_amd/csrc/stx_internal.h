@@ -66,7 +66,7 @@ void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
 // One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
 // changed nothing.  changed[] must be zeroed before pass 0.
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count);
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
                          const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);
