@@ -63,6 +63,9 @@ struct StencilArgs {
     uint8_t* codes;  // optional per-pixel LBP codes [frame][H][W]
 };
 
+// sign bit of v appended below acc: (acc << 1) | (v >> 31)
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v) { return __builtin_amdgcn_alignbit(acc, v, 31); }
+
 template <bool BORDER, bool DO_LBP, bool CODES>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, int frame, int x0, int y0, int lane,
                                       int wv, uint32_t* red /*[16] per wave*/) {
@@ -70,12 +73,12 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     const int x = x0 + lane;
     const int ys = y0 + wv * WAVE_ROWS;
     const int lc = lane + GRAY_XOFF;  // LDS column of pixel x
-    const bool xin = x < W;
+    const bool xin = !BORDER || x < W;
 
-    // LDS column indices for the Canny (replicated border) view
-    int cc[5];
+    // LDS column indices of x-1, x, x+1 in the Canny (replicated border) view
+    int cc[3];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) cc[j] = BORDER ? (iclamp(x + j - 2, 0, W - 1) - x0 + GRAY_XOFF) : (lc + j - 2);
+    for (int j = 0; j < 3; ++j) cc[j] = BORDER ? (iclamp(x + j - 1, 0, W - 1) - x0 + GRAY_XOFF) : (lc + j - 1);
 
     // per-column LBP weights
     double dcP = 0, dcN = 0;
@@ -87,68 +90,83 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     }
     const float wcP = (float)dcP, wcN = (float)dcN;
 
+    // Sobel magnitude of the Canny view at any pixel of the strip's neighbourhood (dynamic LDS
+    // indices; used for the two halo columns only)
+    auto mag_at = [&](int yy, int xx) -> int {
+        if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0;
+        int v[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ry = BORDER ? iclamp(yy + r - 1, 0, H - 1) : yy + r - 1;
+                const int rx = BORDER ? iclamp(xx + q - 1, 0, W - 1) : xx + q - 1;
+                v[r][q] = tile[(ry - y0 + 2) * LPITCH + (rx - x0 + GRAY_XOFF)];
+            }
+        const int gx = (v[0][2] - v[0][0]) + 2 * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0]);
+        const int gy = (v[2][0] - v[0][0]) + 2 * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2]);
+        return abs(gx) + abs(gy);
+    };
+    // The magnitudes left of lane 0 and right of lane 63 belong to the neighbouring strips: lane l
+    // computes them once for row ys-1+l, the marching loop fetches them with a lane read.
+    int haloL = 0, haloR = 0;
+    if (lane < WAVE_ROWS + 2) {
+        haloL = mag_at(ys - 1 + lane, x0 - 1);
+        haloR = mag_at(ys - 1 + lane, x0 + TILE_W);
+    }
+
     // sliding state
     int g[5][5];   // reflected view, rows y-2..y+2, cols x-2..x+2
     int hg[5];     // horizontal [1 4 6 4 1] of those rows
-    int sd[3][3];  // horizontal Sobel difference of rows y, y+1, y+2 (Canny view) at x-1,x,x+1
-    int ss[3][3];  // horizontal Sobel smoothing of the same
+    int rs[5];     // g[r][1]+g[r][2]+g[r][3]
+    int sd[3];     // horizontal Sobel difference at x of rows y, y+1, y+2 (Canny view)
+    int ss[3];     // horizontal Sobel smoothing at x of the same rows
     int mag[3][3]; // L1 magnitude rows y-1..y+1, cols x-1..x+1 (0 outside the image)
     int dxc[2], dyc[2];  // gradient at (y,x) and (y+1,x)
 
-    auto load_row = [&](int r, int (&gr)[5], int& hsum, int (&d)[3], int (&s)[3]) {
+    auto load_row = [&](int r, int (&gr)[5], int& hsum, int& rsum, int& d, int& sm) {
         // r: global row index in [y0-2, y0+TILE_H+1]
         const uint8_t* rowp = tile + (r - y0 + 2) * LPITCH;
 #pragma unroll
         for (int j = 0; j < 5; ++j) gr[j] = rowp[lc + j - 2];
+        rsum = gr[1] + gr[2] + gr[3];
         hsum = gr[0] + gr[4] + 4 * (gr[1] + gr[3]) + 6 * gr[2];
-        int c5[5];
+        int c3[3];
         if (BORDER) {
             const uint8_t* rowc = tile + (iclamp(r, 0, H - 1) - y0 + 2) * LPITCH;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) c5[j] = rowc[cc[j]];
+            for (int j = 0; j < 3; ++j) c3[j] = rowc[cc[j]];
         } else {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) c5[j] = gr[j];
+            for (int j = 0; j < 3; ++j) c3[j] = gr[j + 1];
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            d[j] = c5[j + 2] - c5[j];
-            s[j] = c5[j] + 2 * c5[j + 1] + c5[j + 2];
-        }
+        d = c3[2] - c3[0];
+        sm = c3[0] + 2 * c3[1] + c3[2];
     };
-    auto sobel_row = [&](int r, const int (&d0)[3], const int (&d1)[3], const int (&d2)[3], const int (&s0)[3],
-                         const int (&s2)[3], int (&m)[3], int& gx, int& gy) {
-        // gradient of row r from the three rows r-1, r, r+1
-        const bool rin = !BORDER || (r >= 0 && r < H);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int ddx = d0[j] + 2 * d1[j] + d2[j];
-            const int ddy = s2[j] - s0[j];
-            int mm = abs(ddx) + abs(ddy);
-            if (BORDER) {
-                const int xx = x + j - 1;
-                if (!rin || xx < 0 || xx >= W) mm = 0;
-            }
-            m[j] = mm;
-            if (j == 1) { gx = ddx; gy = ddy; }
-        }
-    };
-    // zero-padded pixel for the LBP fix-up (any row/column of the tile, dynamic indices)
-    auto lbp_px = [&](int yy, int xx) -> double {
-        if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
-        return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+    // gradient and magnitudes of row r (rows r-1, r, r+1 are d0/s0, d1, d2/s2); the neighbours'
+    // magnitudes come from the adjacent lanes
+    auto sobel_row = [&](int r, int d0, int d1, int d2, int s0, int s2, int (&m)[3], int& gx, int& gy) {
+        gx = d0 + 2 * d1 + d2;
+        gy = s2 - s0;
+        int mm = abs(gx) + abs(gy);
+        if (BORDER && (r < 0 || r >= H || x >= W)) mm = 0;
+        const int rel = r - (ys - 1);
+        const int hl = __builtin_amdgcn_readlane(haloL, rel);
+        const int hr = __builtin_amdgcn_readlane(haloR, rel);
+        m[0] = __builtin_amdgcn_update_dpp(hl, mm, 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 keeps hl
+        m[1] = mm;
+        m[2] = __builtin_amdgcn_update_dpp(hr, mm, 0x130, 0xf, 0xf, false);  // wave_shl:1, lane 63 keeps hr
     };
 
     // prologue: rows ys-2 .. ys+1
-    int dtmp[3], stmp[3];
-    load_row(ys - 2, g[0], hg[0], dtmp, stmp);
-    int dm1[3], sm1[3];
-    load_row(ys - 1, g[1], hg[1], dm1, sm1);
-    load_row(ys, g[2], hg[2], sd[0], ss[0]);
-    load_row(ys + 1, g[3], hg[3], sd[1], ss[1]);
+    int dm2, sm2, dm1, sm1;
+    load_row(ys - 2, g[0], hg[0], rs[0], dm2, sm2);
+    load_row(ys - 1, g[1], hg[1], rs[1], dm1, sm1);
+    load_row(ys, g[2], hg[2], rs[2], sd[0], ss[0]);
+    load_row(ys + 1, g[3], hg[3], rs[3], sd[1], ss[1]);
     {
         int gx, gy;
-        sobel_row(ys - 1, dtmp, dm1, sd[0], stmp, ss[0], mag[0], gx, gy);
+        sobel_row(ys - 1, dm2, dm1, sd[0], sm2, ss[0], mag[0], gx, gy);
         sobel_row(ys, dm1, sd[0], sd[1], sm1, ss[1], mag[1], dxc[0], dyc[0]);
     }
 
@@ -158,23 +176,23 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 #pragma unroll 1
     for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
         const int yb = ys + blk * BLOCK_ROWS;
-        if (yb >= H) break;  // wave-uniform: nothing left in the image
-        unsigned long long bits64 = 0;  // 8 LBP bits per row of this block
-        uint32_t pend = 0;              // bit 4*row+k: diagonal sample k of that row needs the fp64 evaluation
+        if (BORDER && yb >= H) break;  // wave-uniform: nothing left in the image
+        // LBP state of this block: per row one byte of SIGN bits (1 = sample below the centre), pushed
+        // in sample order 0..7 (so sample s sits at bit 7-s), and four "needs fp64" flags
+        // (diagonal sample 2k+1 at bit 3-k).
+        unsigned long long sign64 = 0;
+        uint32_t pend = 0;
 #pragma unroll
         for (int i = 0; i < BLOCK_ROWS; ++i) {
             const int y = yb + i;
-            load_row(y + 2, g[4], hg[4], sd[2], ss[2]);
+            load_row(y + 2, g[4], hg[4], rs[4], sd[2], ss[2]);
             sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
-            const bool valid = xin && (y < H);
+            const bool valid = !BORDER || (xin && (y < H));
             const int c = g[2][2];
 
             // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
             {
-                int s9 = 0;
-#pragma unroll
-                for (int r = 1; r <= 3; ++r) s9 += g[r][1] + g[r][2] + g[r][3];
-                const int v = iclamp(9 * c - s9, 0, 255);
+                const int v = iclamp(9 * c - (rs[1] + rs[2] + rs[3]), 0, 255);
                 if (valid) { hp_s += v; hp_q += v * v; gr_s += c; }
             }
             // ---- Gaussian residual
@@ -203,29 +221,45 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 const double rfp = (double)y + a.rp_pos;
                 const float wrP = (float)(rfp - floor(rfp));
                 const int ce = n[1][1];
-                // The four axis samples have integer coordinates: the interpolation returns the pixel
-                // itself, so the comparison is an integer one.
-                uint32_t bits = (n[1][2] >= ce ? 1u : 0u) | (n[0][1] >= ce ? 4u : 0u) | (n[1][0] >= ce ? 16u : 0u) |
-                                (n[2][1] >= ce ? 64u : 0u);
-                // Diagonal samples in fp32: its value is within 2e-4 of the exact bilinear value and the
+                float f[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) f[r][q] = (float)n[r][q];
+                // Row-wise interpolation of the left cell (columns x-1,x; weight dcN) and the right cell
+                // (columns x,x+1; weight dcP); the middle row serves two samples each.
+                float lL[3], lR[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    lL[r] = __builtin_fmaf(wcN, f[r][1] - f[r][0], f[r][0]);
+                    lR[r] = __builtin_fmaf(wcP, f[r][2] - f[r][1], f[r][1]);
+                }
+                // Diagonal samples in fp32: the value is within 2e-4 of the exact bilinear value and the
                 // fp64 sequence within 1e-12, so |value - centre| >= 1e-3 settles the sign; anything
                 // closer is queued for the order-exact fp64 evaluation after this block.
-                uint32_t unc = 0;
-                auto diag = [&](int tl, int tr, int bl, int br, float wr, float wc, int k) {
-                    const float top = __builtin_fmaf(wc, (float)(tr - tl), (float)tl);
-                    const float bot = __builtin_fmaf(wc, (float)(br - bl), (float)bl);
-                    const float d = __builtin_fmaf(wr, bot - top, top) - (float)ce;
-                    bits |= (d >= 0.f ? 1u : 0u) << (2 * k + 1);
-                    unc |= (__builtin_fabsf(d) < 1e-3f ? 1u : 0u) << k;
-                };
-                diag(n[0][1], n[0][2], n[1][1], n[1][2], wrN, wcP, 0);  // sample 1 (-.7,+.7)
-                diag(n[0][0], n[0][1], n[1][0], n[1][1], wrN, wcN, 1);  // sample 3 (-.7,-.7)
-                diag(n[1][0], n[1][1], n[2][0], n[2][1], wrP, wcN, 2);  // sample 5 (+.7,-.7)
-                diag(n[1][1], n[1][2], n[2][1], n[2][2], wrP, wcP, 3);  // sample 7 (+.7,+.7)
-                if (valid) {
-                    bits64 |= (unsigned long long)bits << (8 * i);
-                    pend |= unc << (4 * i);
-                }
+                const float fc = f[1][1];
+                const float d1 = __builtin_fmaf(wrN, lR[1] - lR[0], lR[0]) - fc;  // sample 1 (-.7,+.7)
+                const float d3 = __builtin_fmaf(wrN, lL[1] - lL[0], lL[0]) - fc;  // sample 3 (-.7,-.7)
+                const float d5 = __builtin_fmaf(wrP, lL[2] - lL[1], lL[1]) - fc;  // sample 5 (+.7,-.7)
+                const float d7 = __builtin_fmaf(wrP, lR[2] - lR[1], lR[1]) - fc;  // sample 7 (+.7,+.7)
+                // The axis samples have integer coordinates: the interpolation returns the pixel itself.
+                uint32_t sg = 0;
+                sg = push_sign(sg, (uint32_t)(n[1][2] - ce));      // sample 0 (0,+1)
+                sg = push_sign(sg, __float_as_uint(d1));
+                sg = push_sign(sg, (uint32_t)(n[0][1] - ce));      // sample 2 (-1,0)
+                sg = push_sign(sg, __float_as_uint(d3));
+                sg = push_sign(sg, (uint32_t)(n[1][0] - ce));      // sample 4 (0,-1)
+                sg = push_sign(sg, __float_as_uint(d5));
+                sg = push_sign(sg, (uint32_t)(n[2][1] - ce));      // sample 6 (+1,0)
+                sg = push_sign(sg, __float_as_uint(d7));
+                uint32_t un = 0;
+                un = push_sign(un, __float_as_uint(__builtin_fabsf(d1) - 1e-3f));
+                un = push_sign(un, __float_as_uint(__builtin_fabsf(d3) - 1e-3f));
+                un = push_sign(un, __float_as_uint(__builtin_fabsf(d5) - 1e-3f));
+                un = push_sign(un, __float_as_uint(__builtin_fabsf(d7) - 1e-3f));
+                if (!valid) un = 0;
+                sign64 |= (unsigned long long)sg << (8 * i);
+                pend |= un << (4 * i);
             }
             // ---- Canny non-maximum suppression + double threshold
             {
@@ -253,7 +287,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 if (!valid) cls = 0;
                 const unsigned long long sb = __ballot(cls == 2);
                 const unsigned long long cb = __ballot(cls >= 1);
-                if (lane == 0 && y < H) {
+                if (lane == 0 && (!BORDER || y < H)) {
                     const int64_t wi = ((int64_t)frame * H + y) * a.wpr + (x0 >> 6);
                     a.strong[wi] = sb;
                     a.cand[wi] = cb;
@@ -265,26 +299,30 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 #pragma unroll
                 for (int j = 0; j < 5; ++j) g[r][j] = g[r + 1][j];
                 hg[r] = hg[r + 1];
+                rs[r] = rs[r + 1];
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r) {
+                sd[r] = sd[r + 1];
+                ss[r] = ss[r + 1];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    sd[r][j] = sd[r + 1][j];
-                    ss[r][j] = ss[r + 1][j];
-                    mag[r][j] = mag[r + 1][j];
-                }
+                for (int j = 0; j < 3; ++j) mag[r][j] = mag[r + 1][j];
+            }
             dxc[0] = dxc[1];
             dyc[0] = dyc[1];
         }
         if (DO_LBP) {
             // ---- LBP second stage: near-ties, one (row, sample) per lane and iteration, in the fp64
             // arithmetic of skimage's bilinear_interpolation (operands re-read from the LDS tile)
+            auto lbp_px = [&](int yy, int xx) -> double {
+                if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
+                return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+            };
             while (__any(pend != 0)) {
                 if (pend != 0) {
                     const int b = __ffs(pend) - 1;
                     pend &= pend - 1;
-                    const int i = b >> 2, k = b & 3;
+                    const int i = b >> 2, k = 3 - (b & 3);  // diagonal sample 2k+1 of row i
                     const int y = yb + i;
                     const int r0 = (k >= 2) ? y : y - 1;             // upper row of the 2x2 cell
                     const int c0 = (k == 1 || k == 2) ? x - 1 : x;  // left column of the cell
@@ -293,18 +331,19 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     const double dc = (k == 1 || k == 2) ? dcN : dcP;
                     const uint32_t bit = lbp_bit(lbp_px(r0, c0), lbp_px(r0, c0 + 1), lbp_px(r0 + 1, c0),
                                                  lbp_px(r0 + 1, c0 + 1), dr, dc, lbp_px(y, x));
-                    const int pos = 8 * i + 2 * k + 1;
-                    bits64 = (bits64 & ~(1ull << pos)) | ((unsigned long long)bit << pos);
+                    const int pos = 8 * i + 7 - (2 * k + 1);
+                    sign64 = (sign64 & ~(1ull << pos)) | ((unsigned long long)(bit ^ 1u) << pos);
                 }
             }
-            // ---- codes and histogram of this block
+            // ---- codes and histogram of this block (bit order is reversed, which changes neither
+            // the number of 0/1 transitions between consecutive samples nor the number of ones)
 #pragma unroll
             for (int i = 0; i < BLOCK_ROWS; ++i) {
                 const int y = yb + i;
-                const uint32_t bits = (uint32_t)(bits64 >> (8 * i)) & 0xFFu;
+                const uint32_t bits = ~(uint32_t)(sign64 >> (8 * i)) & 0xFFu;
                 const int changes = __popc((bits ^ (bits >> 1)) & 0x7Fu);
                 const int code = (changes <= 2) ? __popc(bits) : 9;
-                if (xin && y < H) {
+                if (!BORDER || (xin && y < H)) {
                     hist6 += 1ull << (6 * code);
                     if (CODES) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)code;
                 }
