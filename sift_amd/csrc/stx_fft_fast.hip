@@ -54,8 +54,16 @@ constexpr Tw<R> make_tw() {
     return t;
 }
 
+// Complex product in two packed instructions.  The operand-select / negate modifiers of the
+// packed-f32 ops do the shuffling that a straightforward (x*x - y*y, x*y + y*x) needs extra
+// moves for:  t = (a.y * -b.y, a.y * b.x);  r = (a.x * b.x + t.x, a.x * b.y + t.y).
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    const v2f va = __builtin_bit_cast(v2f, a), vb = __builtin_bit_cast(v2f, b);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(va), "v"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+    return __builtin_bit_cast(float2, r);
 }
 
 // v * exp(-2 pi i m / R) for compile-time-foldable m
@@ -65,7 +73,7 @@ __device__ __forceinline__ float2 mul_tw(float2 v, int m, const Tw<R>& tw) {
     if (4 * m == R) return make_float2(v.y, -v.x);
     if (2 * m == R) return make_float2(-v.x, -v.y);
     if (4 * m == 3 * R) return make_float2(-v.y, v.x);
-    return make_float2(v.x * tw.re[m] - v.y * tw.im[m], v.x * tw.im[m] + v.y * tw.re[m]);
+    return cmulf(v, make_float2(tw.re[m], tw.im[m]));
 }
 
 // ---------------------------------------------------------------- register DFTs
@@ -237,49 +245,105 @@ struct RowsArgs {
     int foy, fox, fh, fwh;
     int cbw, nkb;  // column-block width (a power of two) and count of the spectrum layout
     int cbw_log2;
+    int groups;       // groups of TPW row pairs per frame
+    int total_units;  // n_frames * groups
     const float2* tw;
     float2* spec;
 };
 
+// Persistent waves: each wave walks over (frame, row pair) units with a stride of the grid size and
+// issues the global loads of its NEXT unit before transforming the current one, so the HBM/L2
+// latency of the gray rows hides behind the butterflies.
 template <class P>
 __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
-    __shared__ float2 lds[P::TPW * P::S];
+    __shared__ __attribute__((aligned(16))) float2 lds[P::TPW * P::S];
     constexpr int N = P::N, LPT = P::LPT;
+    constexpr bool PREFETCH = (P::TPW == 1) && (N % 4 == 0);
+    constexpr int NL = PREFETCH ? (N / 4 + 63) / 64 : 1;  // dwords per lane and row
     const int lane = threadIdx.x;
     const int sub = lane / LPT, t = lane % LPT;
-    const int frame = blockIdx.y;
-    const int tr = blockIdx.x * P::TPW + sub;  // row pair
-    const int ra = 2 * tr, rb = ra + 1;
     float2* buf = lds + sub * P::S;
-    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
-    const uint8_t* pa = gp + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
-    const uint8_t* pb = pa + a.gpitch;
-    const bool ina = ra < a.fh, inb = rb < a.fh;
-    if ((N % 4 == 0) && ((a.fox & 3) == 0)) {
-        for (int x4 = t; x4 < N / 4; x4 += LPT) {
-            const uint32_t wa = ina ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
-            const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : 0x80808080u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                buf[pad<P::SWZ>(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
-                                                   (float)((int)((wb >> (8 * q)) & 255u) - 128));
-        }
-    } else {
-        for (int x = t; x < N; x += LPT)
-            buf[pad<P::SWZ>(x)] = make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
-    }
-    transform<P>(buf, a.tw, t);
-    if (!ina) return;
-    // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
     const int cbw = a.cbw;
-    float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw;
-    for (int k = t; k <= N / 2; k += LPT) {
-        const float2 zk = buf[pad<P::SWZ>(k)];
-        const float2 zc = buf[pad<P::SWZ>(k ? N - k : 0)];
-        const int kb = k >> a.cbw_log2, kc = k & (cbw - 1);
-        float2* o = base + (((int64_t)kb * a.fh + ra) << a.cbw_log2) + kc;
-        o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    const bool aligned = (a.fox & 3) == 0;
+
+    uint32_t ra_reg[NL], rb_reg[NL];
+    auto row_ptr = [&](int unit, int& frame, int& ra) -> const uint8_t* {
+        frame = unit / a.groups;
+        const int grp = unit - frame * a.groups;
+        ra = 2 * (grp * P::TPW + sub);
+        return a.gray + (int64_t)frame * a.grows * a.gpitch + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox +
+               GRAY_XOFF;
+    };
+    auto fetch = [&](int unit) {
+        int frame, ra;
+        const uint8_t* pa = row_ptr(unit, frame, ra);
+        const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int x4 = lane + 64 * i;
+            const bool inx = (NL * 64 == N / 4) || x4 < N / 4;
+            ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
+            rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0x80808080u;
+        }
+    };
+
+    int unit = blockIdx.x;
+    if (PREFETCH && aligned && unit < a.total_units) fetch(unit);
+    for (; unit < a.total_units; unit += gridDim.x) {
+        int frame, ra;
+        const uint8_t* pa = row_ptr(unit, frame, ra);
+        const uint8_t* pb = pa + a.gpitch;
+        const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
+        if (PREFETCH && aligned) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int x4 = lane + 64 * i;
+                if ((NL * 64 == N / 4) || x4 < N / 4) {
+                    const uint32_t wa = ra_reg[i], wb = rb_reg[i];
+                    float2 e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        e[q] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
+                                           (float)((int)((wb >> (8 * q)) & 255u) - 128));
+                    if constexpr (!P::SWZ) {
+                        // 16-byte stores: half the bank conflicts of four strided 8-byte stores
+                        float4* d4 = reinterpret_cast<float4*>(buf + 4 * x4);
+                        d4[0] = make_float4(e[0].x, e[0].y, e[1].x, e[1].y);
+                        d4[1] = make_float4(e[2].x, e[2].y, e[3].x, e[3].y);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) buf[pad<P::SWZ>(4 * x4 + q)] = e[q];
+                    }
+                }
+            }
+            if (unit + (int)gridDim.x < a.total_units) fetch(unit + gridDim.x);
+        } else if ((N % 4 == 0) && aligned) {
+            for (int x4 = t; x4 < N / 4; x4 += LPT) {
+                const uint32_t wa = ina ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
+                const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : 0x80808080u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    buf[pad<P::SWZ>(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
+                                                               (float)((int)((wb >> (8 * q)) & 255u) - 128));
+            }
+        } else {
+            for (int x = t; x < N; x += LPT)
+                buf[pad<P::SWZ>(x)] =
+                    make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
+        }
+        transform<P>(buf, a.tw, t);
+        if (ina) {
+            // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
+            float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw;
+            for (int k = t; k <= N / 2; k += LPT) {
+                const float2 zk = buf[pad<P::SWZ>(k)];
+                const float2 zc = buf[pad<P::SWZ>(k ? N - k : 0)];
+                const int kb = k >> a.cbw_log2, kc = k & (cbw - 1);
+                float2* o = base + (((int64_t)kb * a.fh + ra) << a.cbw_log2) + kc;
+                o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+                if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+            }
+        }
     }
 }
 
@@ -327,8 +391,10 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
         for (int y = t; y < N; y += LPT) {
             float2 v = buf[pad<P::SWZ>(y)];
             if (k == 0 && y == 0) v.x += dc_fix;
-            const float mag = sqrtf(v.x * v.x + v.y * v.y);
-            const double l = (double)logf(mag + 1.0f);
+            // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
+            // the statistic; the sums stay in fp64 because the variance is a small difference
+            const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+            const double l = (double)(__builtin_amdgcn_logf(mag + 1.0f) * 0.69314718055994530942f);
             ls += l;
             ls2 += l * l;
         }
@@ -371,10 +437,16 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     X(2048, 16, 16, 8, 1, 64)
 
 template <class P>
-void launch_rows_t(hipStream_t s, const RowsArgs& a, int n_frames) {
+void launch_rows_t(hipStream_t s, RowsArgs a, int n_frames) {
     const int pairs = (a.fh + 1) / 2;
-    dim3 grid((pairs + P::TPW - 1) / P::TPW, n_frames);
-    hipLaunchKernelGGL(rows_kernel<P>, grid, dim3(64), 0, s, a);
+    a.groups = (pairs + P::TPW - 1) / P::TPW;
+    a.total_units = n_frames * a.groups;
+    // as many single-wave workgroups as the LDS of 256 CUs holds at once (at most 16 per CU)
+    const int lds_bytes = P::TPW * P::S * (int)sizeof(float2);
+    int per_cu = (160 * 1024) / (lds_bytes + 256);
+    per_cu = per_cu > 16 ? 16 : (per_cu < 1 ? 1 : per_cu);
+    const int grid = a.total_units < 256 * per_cu ? a.total_units : 256 * per_cu;
+    hipLaunchKernelGGL(rows_kernel<P>, dim3(grid), dim3(64), 0, s, a);
 }
 
 template <class P>
