@@ -158,6 +158,7 @@ void orc_gauss5(const uint8_t* gray, int h, int w, uint8_t* out) {
  * 13573/2^15), double threshold, 8-connected hysteresis. */
 int orc_canny(const uint8_t* gray, int h, int w, int low, int high, uint8_t* edges, uint8_t* nms_map) {
     size_t n = (size_t)h * (size_t)w;
+    if (low > high) { int t = low; low = high; high = t; } /* cv::Canny swaps reversed thresholds */
     int16_t* dx = (int16_t*)malloc(n * sizeof(int16_t));
     int16_t* dy = (int16_t*)malloc(n * sizeof(int16_t));
     /* magnitude with a one-pixel zero frame */

@@ -235,6 +235,8 @@ def np_canny(gray: np.ndarray, low: int = 50, high: int = 150):
     """cv2.Canny(gray, 50, 150), passive_checker.py:116.  Returns (edges u8 0/255, nms map 0/1/2)."""
     from scipy import ndimage
     h, w = gray.shape
+    if low > high:  # cv2.Canny swaps reversed thresholds
+        low, high = high, low
     g = np.pad(gray.astype(np.int64), 1, mode="edge")  # BORDER_REPLICATE
     gx = (g[:-2, 2:] - g[:-2, :-2]) + 2 * (g[1:-1, 2:] - g[1:-1, :-2]) + (g[2:, 2:] - g[2:, :-2])
     gy = (g[2:, :-2] - g[:-2, :-2]) + 2 * (g[2:, 1:-1] - g[:-2, 1:-1]) + (g[2:, 2:] - g[:-2, 2:])

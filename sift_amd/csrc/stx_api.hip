@@ -274,6 +274,7 @@ int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
     if (params) pr->p = *params; else stx_default_params(&pr->p);
     int rc;
     if ((rc = check_params(c, pr->p)) != STX_OK) return rc;
+    if (pr->p.canny_low > pr->p.canny_high) std::swap(pr->p.canny_low, pr->p.canny_high);  // cv2.Canny swaps them
     if ((rc = make_geom(c, h, w, pr->p, &pr->g)) != STX_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if (!make_fft_plan(pr->g.fw, &pr->plan_w) || !make_fft_plan(pr->g.fh, &pr->plan_h))

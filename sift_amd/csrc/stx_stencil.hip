@@ -182,6 +182,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         // (diagonal sample 2k+1 at bit 3-k).
         unsigned long long sign64 = 0;
         uint32_t pend = 0;
+        unsigned long long bm_s = 0, bm_c = 0;
 #pragma unroll
         for (int i = 0; i < BLOCK_ROWS; ++i) {
             const int y = yb + i;
@@ -261,37 +262,35 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 sign64 |= (unsigned long long)sg << (8 * i);
                 pend |= un << (4 * i);
             }
-            // ---- Canny non-maximum suppression + double threshold
+            // ---- Canny non-maximum suppression + double threshold, branch-free: pick the two
+            // neighbours along the quantised gradient direction, then two compares.  The second
+            // neighbour is compared with >= for horizontal / vertical gradients and with > for
+            // diagonal ones; for integers m >= b is m > b-1.
             {
                 const int m = mag[1][1];
-                int cls = 0;
-                if (m > a.low) {
+                unsigned long long sb = 0, cb = 0;
+                // most rows of a smooth image have no pixel above the low threshold: one wave-uniform
+                // test skips the whole selection for them
+                if (__any(m > a.low && valid)) {
                     const int xs = dxc[0], ysg = dyc[0];
                     const int ax = abs(xs), ay = abs(ysg) << 15;
                     const int tg22x = ax * 13573;
-                    bool keep;
-                    if (ay < tg22x) {
-                        keep = (m > mag[1][0]) && (m >= mag[1][2]);
-                    } else {
-                        const int tg67x = tg22x + (ax << 16);
-                        if (ay > tg67x) {
-                            keep = (m > mag[0][1]) && (m >= mag[2][1]);
-                        } else if ((xs ^ ysg) < 0) {
-                            keep = (m > mag[0][2]) && (m > mag[2][0]);
-                        } else {
-                            keep = (m > mag[0][0]) && (m > mag[2][2]);
-                        }
-                    }
-                    if (keep) cls = (m > a.high) ? 2 : 1;
+                    const int tg67x = tg22x + (ax << 16);
+                    const bool horiz = ay < tg22x;
+                    const bool vert = ay > tg67x;
+                    const bool opp = (xs ^ ysg) < 0;
+                    int na = opp ? mag[0][2] : mag[0][0];
+                    int nb = opp ? mag[2][0] : mag[2][2];
+                    na = vert ? mag[0][1] : na;
+                    nb = vert ? mag[2][1] - 1 : nb;
+                    na = horiz ? mag[1][0] : na;
+                    nb = horiz ? mag[1][2] - 1 : nb;
+                    const bool keep = (m > na) && (m > nb) && valid;
+                    sb = __ballot(keep && m > a.high);
+                    cb = __ballot(keep && m > a.low);
                 }
-                if (!valid) cls = 0;
-                const unsigned long long sb = __ballot(cls == 2);
-                const unsigned long long cb = __ballot(cls >= 1);
-                if (lane == 0 && (!BORDER || y < H)) {
-                    const int64_t wi = ((int64_t)frame * H + y) * a.wpr + (x0 >> 6);
-                    a.strong[wi] = sb;
-                    a.cand[wi] = cb;
-                }
+                // park the two bitmap words of row i in lane i; lanes 0..7 store them after the block
+                if (lane == i) { bm_s = sb; bm_c = cb; }
             }
             // ---- slide down one row
 #pragma unroll
@@ -310,6 +309,11 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             }
             dxc[0] = dxc[1];
             dyc[0] = dyc[1];
+        }
+        if (lane < BLOCK_ROWS && (!BORDER || yb + lane < H)) {
+            const int64_t wi = ((int64_t)frame * H + yb + lane) * a.wpr + (x0 >> 6);
+            a.strong[wi] = bm_s;
+            a.cand[wi] = bm_c;
         }
         if (DO_LBP) {
             // ---- LBP second stage: near-ties, one (row, sample) per lane and iteration, in the fp64
