@@ -115,6 +115,15 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         haloR = mag_at(ys - 1 + lane, x0 + TILE_W);
     }
 
+    // fp32 row weights of the LBP samples above / below row ys+lane (lanes 0..31)
+    int rowWN = 0, rowWP = 0;
+    if (DO_LBP) {
+        const double rfn = (double)(ys + lane) + a.rp_neg;
+        rowWN = __float_as_int((float)(rfn - floor(rfn)));
+        const double rfp = (double)(ys + lane) + a.rp_pos;
+        rowWP = __float_as_int((float)(rfp - floor(rfp)));
+    }
+
     // sliding state
     int g[5][5];   // reflected view, rows y-2..y+2, cols x-2..x+2
     int hg[5];     // horizontal [1 4 6 4 1] of those rows
@@ -216,11 +225,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         }
                         n[r][q] = v;
                     }
-                // rows are wave-uniform: the weights cost a handful of fp64 operations per row
-                const double rfn = (double)y + a.rp_neg;
-                const float wrN = (float)(rfn - floor(rfn));
-                const double rfp = (double)y + a.rp_pos;
-                const float wrP = (float)(rfp - floor(rfp));
+                // the row weights are wave-uniform: lane l computed those of row ys+l before the loop
+                const float wrN = __int_as_float(__builtin_amdgcn_readlane(rowWN, blk * BLOCK_ROWS + i));
+                const float wrP = __int_as_float(__builtin_amdgcn_readlane(rowWP, blk * BLOCK_ROWS + i));
                 const int ce = n[1][1];
                 float f[3][3];
 #pragma unroll
