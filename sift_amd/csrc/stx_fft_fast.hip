@@ -187,6 +187,17 @@ struct Plan {
     static_assert(SWZ || (R0_ & 1), "sizes with an odd factor must start with an odd radix");
 };
 
+// Lanes of a wave exchange data through LDS with no barrier instruction: the hardware executes
+// a wave's LDS operations in issue order.  The COMPILER, however, reasons per thread and may
+// move a lane's load above its own earlier store when it can prove the two addresses differ for
+// that lane — which breaks the exchange with other lanes.  This fence (wavefront scope: no
+// instruction is emitted) pins the order at every phase boundary.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool SWZ>
 __device__ __forceinline__ int pad(int i) {
     return SWZ ? (i ^ ((i >> 4) & 15)) : i;
@@ -207,6 +218,7 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
                 for (int r = 0; r < R; ++r) v[it][r] = buf[pad<SWZ>(j + r * M)];
             }
         }
+        wave_sync();  // every lane has read its inputs before any lane overwrites them
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int j = t + it * LPT;
@@ -227,11 +239,13 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
                 for (int r = 0; r < R; ++r) buf[pad<SWZ>(o + r * NS)] = v[it][r];
             }
         }
+        wave_sync();  // the next phase reads what other lanes wrote
     }
 }
 
 template <class P>
 __device__ __forceinline__ void transform(float2* buf, const float2* twg, int t) {
+    wave_sync();  // the signal was stored by other lanes
     pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, twg, t);
     pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t);
     pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t);
@@ -344,6 +358,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                 if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
             }
         }
+        wave_sync();  // the next unit's signal overwrites what other lanes have just read
     }
 }
 

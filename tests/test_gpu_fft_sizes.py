@@ -1,0 +1,33 @@
+"""Every compile-time-planned FFT length, as a row transform and as a column transform, against
+numpy (np.fft.fft2 -> log(abs+1) -> std, /root/reference/app/passive_checker.py:120-123)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FAST_SIZES = [64, 80, 96, 128, 160, 240, 256, 320, 360, 480, 512, 540, 640, 720, 768, 960, 1024, 1080, 1280, 1440,
+              1920, 2048]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sift_amd.texture import TextureContext
+    c = TextureContext(0)
+    yield c
+    c.close()
+
+
+def _ref(gray):
+    return float(np.std(np.log(np.abs(np.fft.fft2(gray)) + 1)))
+
+
+@pytest.mark.parametrize("n", FAST_SIZES)
+def test_fast_fft_length(ctx, n):
+    rng = np.random.default_rng(n)
+    # 66 has no planned kernel, so each case isolates one planned transform; the square case runs both
+    for (h, w) in ((n, 66), (66, n), (n, n) if n <= 512 else (n, 64)):
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        bgr = np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))
+        r = ctx.analyze_frames([bgr, bgr[::-1].copy()])
+        assert r[0].frequency_anomaly == pytest.approx(_ref(g), rel=1e-5), (h, w)
+        assert r[1].frequency_anomaly == pytest.approx(_ref(g[::-1]), rel=1e-5), (h, w)
