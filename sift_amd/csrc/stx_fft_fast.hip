@@ -204,8 +204,16 @@ __device__ __forceinline__ int pad(int i) {
 }
 
 // One Stockham pass of radix R; NS = product of the radices already applied.
-template <int N, int R, int NS, int LPT, bool SWZ>
-__device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t) {
+// Where a pass puts its outputs: back into the LDS buffer, or (last pass of the column
+// transform) straight into a consumer, which saves one LDS write and one LDS read per element.
+template <bool SWZ>
+struct StoreSink {
+    float2* buf;
+    __device__ __forceinline__ void operator()(int idx, float2 v) const { buf[pad<SWZ>(idx)] = v; }
+};
+
+template <int N, int R, int NS, int LPT, bool SWZ, class Sink>
+__device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t, Sink& sink) {
     if constexpr (R > 1) {
         constexpr int M = N / R;
         constexpr int ITER = (M + LPT - 1) / LPT;
@@ -236,20 +244,33 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
                 Dft<R>::run(v[it]);
                 const int o = (j - k) * R + k;
 #pragma unroll
-                for (int r = 0; r < R; ++r) buf[pad<SWZ>(o + r * NS)] = v[it][r];
+                for (int r = 0; r < R; ++r) sink(o + r * NS, v[it][r]);
             }
         }
         wave_sync();  // the next phase reads what other lanes wrote
     }
 }
 
+// last: receives the outputs of the final pass (index, value) instead of the LDS buffer
+template <class P, class Sink>
+__device__ __forceinline__ void transform_to(float2* buf, const float2* twg, int t, Sink& last) {
+    constexpr int NP = (P::R3 > 1) ? 4 : (P::R2 > 1) ? 3 : (P::R1 > 1) ? 2 : 1;
+    StoreSink<P::SWZ> st{buf};
+    wave_sync();  // the signal was stored by other lanes
+    if constexpr (NP == 1) pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, twg, t, st);
+    if constexpr (NP == 2) pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t, st);
+    if constexpr (NP == 3) pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t, st);
+    if constexpr (NP == 4) pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t, st);
+}
+
 template <class P>
 __device__ __forceinline__ void transform(float2* buf, const float2* twg, int t) {
-    wave_sync();  // the signal was stored by other lanes
-    pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, twg, t);
-    pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t);
-    pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t);
-    pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t);
+    StoreSink<P::SWZ> st{buf};
+    transform_to<P>(buf, twg, t, st);
 }
 
 // ---------------------------------------------------------------- kernels
@@ -399,13 +420,13 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     const int c = wave * P::TPW + sub;  // column within the block
     float2* buf = dynlds + c * S;
     const int k = kb * cbw + c;
-    transform<P>(buf, a.tw, t);
-    double ls = 0.0, ls2 = 0.0;
-    if (k < a.fwh) {
-        const float dc_fix = 128.0f * (float)N * (float)a.fw;
-        for (int y = t; y < N; y += LPT) {
-            float2 v = buf[pad<P::SWZ>(y)];
-            if (k == 0 && y == 0) v.x += dc_fix;
+    // the last pass hands its outputs straight to the log-magnitude reduction
+    struct LogMagSink {
+        double ls = 0.0, ls2 = 0.0;
+        float dc_fix;
+        bool dc_col;
+        __device__ __forceinline__ void operator()(int y, float2 v) {
+            if (dc_col && y == 0) v.x += dc_fix;
             // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
             // the statistic; the sums stay in fp64 because the variance is a small difference
             const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
@@ -413,7 +434,12 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
             ls += l;
             ls2 += l * l;
         }
-    }
+    } sink;
+    sink.dc_fix = 128.0f * (float)N * (float)a.fw;
+    sink.dc_col = (k == 0);
+    transform_to<P>(buf, a.tw, t, sink);
+    double ls = sink.ls, ls2 = sink.ls2;
+    if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; }  // columns past the half spectrum hold no data
 #pragma unroll
     for (int o = LPT / 2; o > 0; o >>= 1) {
         ls += __shfl_xor(ls, o, 64);

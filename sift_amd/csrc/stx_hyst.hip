@@ -2,7 +2,8 @@
 // on one-bit-per-pixel maps: "strong" grows into every "candidate" pixel that is
 // 8-connected to it, transitively.
 //
-// One wave owns a 64x64 pixel tile: lane = row, one 64-bit word = that row's 64 pixels.
+// One wave owns a 64x64 pixel tile: lane = row, one 64-bit word = that row's 64 pixels
+// (maps are stored [frame][word column][row], so a tile's 64 words are contiguous).
 // Vertical neighbours come from the adjacent lanes, horizontal ones from shifts, and a
 // strong bit floods a whole horizontal run of candidates in O(1) with a carry chain:
 // adding the seed bits to the run mask ripples a carry to the end of each run.  The tile
@@ -52,32 +53,30 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
         }
     }
     const int y = ty * 64 + lane;
-    unsigned long long* sb = strong + (int64_t)frame * H * wpr;
-    const unsigned long long* cb = cand + (int64_t)frame * H * wpr;
+    // bitmaps are stored [frame][word column][row]: the 64 rows of a tile are contiguous
+    unsigned long long* sb = strong + ((int64_t)frame * wpr + wx) * H;
+    const unsigned long long* cb = cand + ((int64_t)frame * wpr + wx) * H;
     const bool rowin = y < H;
     const bool hasl = wx > 0, hasr = wx + 1 < wpr;
     unsigned long long S = 0, C = 0, Lw = 0, Rw = 0;
     if (rowin) {
-        const int64_t i = (int64_t)y * wpr + wx;
-        S = sb[i];
-        C = cb[i];
-        if (hasl) Lw = sb[i - 1];
-        if (hasr) Rw = sb[i + 1];
+        S = sb[y];
+        C = cb[y];
+        if (hasl) Lw = sb[y - H];
+        if (hasr) Rw = sb[y + H];
     }
     // halo rows above and below the tile (own word and its two neighbours)
     unsigned long long To = 0, Tl = 0, Tr = 0, Bo = 0, Bl = 0, Br = 0;
     const int yt = ty * 64 - 1, yb = ty * 64 + 64;
     if (yt >= 0) {
-        const int64_t i = (int64_t)yt * wpr + wx;
-        To = sb[i];
-        if (hasl) Tl = sb[i - 1];
-        if (hasr) Tr = sb[i + 1];
+        To = sb[yt];
+        if (hasl) Tl = sb[yt - H];
+        if (hasr) Tr = sb[yt + H];
     }
     if (yb < H) {
-        const int64_t i = (int64_t)yb * wpr + wx;
-        Bo = sb[i];
-        if (hasl) Bl = sb[i - 1];
-        if (hasr) Br = sb[i + 1];
+        Bo = sb[yb];
+        if (hasl) Bl = sb[yb - H];
+        if (hasr) Br = sb[yb + H];
     }
     unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
     unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
     } while (any);
 
     const bool ch = S != orig;
-    if (ch) sb[(int64_t)y * wpr + wx] = S;
+    if (ch) sb[y] = S;
     const bool tile_changed = __any(ch);
     uint32_t cnt = __popcll(S);
 #pragma unroll
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long l
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)H * W) return;
     const int y = (int)(i / W), x = (int)(i % W);
-    edges[i] = ((strong[(int64_t)y * wpr + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : 0;
+    edges[i] = ((strong[(int64_t)(x >> 6) * H + y] >> (x & 63)) & 1ull) ? 255 : 0;
 }
 
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,

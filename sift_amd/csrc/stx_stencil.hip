@@ -318,7 +318,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             dyc[0] = dyc[1];
         }
         if (lane < BLOCK_ROWS && (!BORDER || yb + lane < H)) {
-            const int64_t wi = ((int64_t)frame * H + yb + lane) * a.wpr + (x0 >> 6);
+            const int64_t wi = ((int64_t)frame * a.wpr + (x0 >> 6)) * H + yb + lane;  // [frame][word column][row]
             a.strong[wi] = bm_s;
             a.cand[wi] = bm_c;
         }
