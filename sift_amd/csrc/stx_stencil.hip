@@ -179,6 +179,32 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         sobel_row(ys, dm1, sd[0], sd[1], sm1, ss[1], mag[1], dxc[0], dyc[0]);
     }
 
+    // LBP row state, sliding with the window: the zero-padded 3 neighbours of rows y-1..y+1, the centre
+    // column as float, and the row-wise interpolations of the left cell (columns x-1,x; weight dcN)
+    // and the right cell (columns x,x+1; weight dcP).  Each image row is converted and interpolated once
+    // and serves the three centre rows that touch it.
+    int nm[3][3];
+    float fcs[3], lLs[3], lRs[3];
+    auto lbp_row = [&](int yy, const int (&gr)[5], int (&nrow)[3], float& fc, float& l_left, float& l_right) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            int v = gr[q + 1];
+            if (BORDER) {
+                const int xx = x + q - 1;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
+            }
+            nrow[q] = v;
+        }
+        const float f0 = (float)nrow[0], f1 = (float)nrow[1], f2 = (float)nrow[2];
+        fc = f1;
+        l_left = __builtin_fmaf(wcN, f1 - f0, f0);
+        l_right = __builtin_fmaf(wcP, f2 - f1, f1);
+    };
+    if (DO_LBP) {
+        lbp_row(ys - 1, g[1], nm[0], fcs[0], lLs[0], lRs[0]);
+        lbp_row(ys, g[2], nm[1], fcs[1], lLs[1], lRs[1]);
+    }
+
     unsigned long long hist6 = 0;  // ten 6-bit counters (at most 32 pixels per lane)
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
 
@@ -213,39 +239,18 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             }
             // ---- LBP (P=8, R=1), first stage
             if (DO_LBP) {
-                int n[3][3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        int v = g[r + 1][q + 1];
-                        if (BORDER) {
-                            const int yy = y + r - 1, xx = x + q - 1;
-                            if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
-                        }
-                        n[r][q] = v;
-                    }
+                lbp_row(y + 1, g[3], nm[2], fcs[2], lLs[2], lRs[2]);  // rows y-1 and y slid in earlier
                 // the row weights are wave-uniform: lane l computed those of row ys+l before the loop
                 const float wrN = __int_as_float(__builtin_amdgcn_readlane(rowWN, blk * BLOCK_ROWS + i));
                 const float wrP = __int_as_float(__builtin_amdgcn_readlane(rowWP, blk * BLOCK_ROWS + i));
+                const int (&n)[3][3] = nm;
+                const float (&lL)[3] = lLs;
+                const float (&lR)[3] = lRs;
                 const int ce = n[1][1];
-                float f[3][3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) f[r][q] = (float)n[r][q];
-                // Row-wise interpolation of the left cell (columns x-1,x; weight dcN) and the right cell
-                // (columns x,x+1; weight dcP); the middle row serves two samples each.
-                float lL[3], lR[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    lL[r] = __builtin_fmaf(wcN, f[r][1] - f[r][0], f[r][0]);
-                    lR[r] = __builtin_fmaf(wcP, f[r][2] - f[r][1], f[r][1]);
-                }
                 // Diagonal samples in fp32: the value is within 2e-4 of the exact bilinear value and the
                 // fp64 sequence within 1e-12, so |value - centre| >= 1e-3 settles the sign; anything
                 // closer is queued for the order-exact fp64 evaluation after this block.
-                const float fc = f[1][1];
+                const float fc = fcs[1];
                 const float d1 = __builtin_fmaf(wrN, lR[1] - lR[0], lR[0]) - fc;  // sample 1 (-.7,+.7)
                 const float d3 = __builtin_fmaf(wrN, lL[1] - lL[0], lL[0]) - fc;  // sample 3 (-.7,-.7)
                 const float d5 = __builtin_fmaf(wrP, lL[2] - lL[1], lL[1]) - fc;  // sample 5 (+.7,-.7)
@@ -316,6 +321,16 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             }
             dxc[0] = dxc[1];
             dyc[0] = dyc[1];
+            if (DO_LBP) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) nm[r][q] = nm[r + 1][q];
+                    fcs[r] = fcs[r + 1];
+                    lLs[r] = lLs[r + 1];
+                    lRs[r] = lRs[r + 1];
+                }
+            }
         }
         if (lane < BLOCK_ROWS && (!BORDER || yb + lane < H)) {
             const int64_t wi = ((int64_t)frame * a.wpr + (x0 >> 6)) * H + yb + lane;  // [frame][word column][row]
