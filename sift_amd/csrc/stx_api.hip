@@ -42,6 +42,7 @@ struct Slot {
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
     hipEvent_t done = nullptr;
+    hipEvent_t gray_ready = nullptr, fft_done = nullptr;
     int passes = 0;  // hysteresis passes queued so far
     int F = 0;
     std::vector<TimedSpan> spans;
@@ -51,6 +52,7 @@ constexpr int N_SLOTS = 2;
 struct stx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_fft = nullptr;  // the FFT kernels run beside the stencil / hysteresis kernels
     std::string err;
     Slot slot[N_SLOTS];
     DevBuf codes, plane;
@@ -109,18 +111,20 @@ struct Span {
     std::vector<TimedSpan>* dst;
     TimedSpan t;
     bool on;
-    Span(stx_ctx* c_, std::vector<TimedSpan>* dst_, int kind, int launches) : c(c_), dst(dst_), on(c_->timing) {
+    hipStream_t st;
+    Span(stx_ctx* c_, std::vector<TimedSpan>* dst_, int kind, int launches, hipStream_t stream = nullptr)
+        : c(c_), dst(dst_), on(c_->timing), st(stream ? stream : c_->stream) {
         if (!on) return;
         t.kind = kind;
         t.launches = launches;
         t.e0 = get_event(c);
         t.e1 = get_event(c);
         if (!t.e0 || !t.e1) { on = false; return; }
-        (void)hipEventRecord(t.e0, c->stream);
+        (void)hipEventRecord(t.e0, st);
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(t.e1, c->stream);
+        (void)hipEventRecord(t.e1, st);
         dst->push_back(t);
     }
 };
@@ -349,6 +353,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         launch_gray(s, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)sl.gray.p);
         sp.end();
     }
+    HIPCHK(c, hipEventRecord(sl.gray_ready, s));
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
     {
         Span sp(c, &sl.spans, STX_K_STENCIL, 1);
@@ -364,15 +369,23 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
     // changed nothing); finish_chunk() checks the last counter and only then adds more
     if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
+    // The FFT pair only needs the gray plane: it runs on a second stream, concurrently with the
+    // stencil and hysteresis kernels (those saturate the VALUs, the FFTs mostly wait on LDS).
     {
-        Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1);
-        launch_fft_rows(s, (const uint8_t*)sl.gray.p, F, g, lay, pr.plan_w, pr.tw_w, (float2*)sl.spec.p);
-        sp.end();
-    }
-    {
-        Span sp(c, &sl.spans, STX_K_FFT_COLS, 1);
-        launch_fft_cols(s, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h, (double2*)sl.part.p);
-        sp.end();
+        hipStream_t sf = c->stream_fft;
+        HIPCHK(c, hipStreamWaitEvent(sf, sl.gray_ready, 0));
+        {
+            Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1, sf);
+            launch_fft_rows(sf, (const uint8_t*)sl.gray.p, F, g, lay, pr.plan_w, pr.tw_w, (float2*)sl.spec.p);
+            sp.end();
+        }
+        {
+            Span sp(c, &sl.spans, STX_K_FFT_COLS, 1, sf);
+            launch_fft_cols(sf, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h, (double2*)sl.part.p);
+            sp.end();
+        }
+        HIPCHK(c, hipEventRecord(sl.fft_done, sf));
+        HIPCHK(c, hipStreamWaitEvent(s, sl.fft_done, 0));
     }
     return queue_results(c, sl, pr);
 }
@@ -459,6 +472,7 @@ int stx_create(int device_id, stx_ctx** out) {
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
     if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
+    if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking); }
     for (int i = 0; i < N_SLOTS && e == hipSuccess; ++i) {
         step = "hipHostMalloc";
         e = hipHostMalloc((void**)&c->slot[i].changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
@@ -467,6 +481,8 @@ int stx_create(int device_id, stx_ctx** out) {
             step = "hipEventCreate";
             e = hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming);
         }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].gray_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].fft_done, hipEventDisableTiming);
     }
     if (e == hipSuccess) { step = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; e = fft_set_lds_limits(); }
     if (e != hipSuccess) {
@@ -482,6 +498,7 @@ int stx_destroy(stx_ctx* c) {
     if (!c) return STX_ERR_INVALID;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
     for (Slot& sl : c->slot) {
         DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
@@ -489,6 +506,8 @@ int stx_destroy(stx_ctx* c) {
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);
         if (sl.changed_host) (void)hipHostFree(sl.changed_host);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.gray_ready) (void)hipEventDestroy(sl.gray_ready);
+        if (sl.fft_done) (void)hipEventDestroy(sl.fft_done);
         for (auto& t : sl.spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     }
     if (c->codes.p) (void)hipFree(c->codes.p);
@@ -496,6 +515,7 @@ int stx_destroy(stx_ctx* c) {
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_fft) (void)hipStreamDestroy(c->stream_fft);
     delete c;
     return STX_OK;
 }
