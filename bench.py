@@ -81,9 +81,18 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # STX_BENCH_BACKEND=gloo STX_BENCH_DEVICE=0 rehearses the multi-rank path on a one-GPU box
+    backend = os.environ.get("STX_BENCH_BACKEND", "nccl")
+    dev_override = os.environ.get("STX_BENCH_DEVICE")
+    if dev_override is not None:
+        local_rank = int(dev_override)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    gather_device = "cuda" if backend == "nccl" else None
 
     from sift_amd._lib import StxMetrics
     from sift_amd.sharding import gather_rows
@@ -124,13 +133,23 @@ def main() -> None:
         step(i, keep=i)
     if world > 1:
         # the one collective of the job: every rank's clips (video id = step*world + rank) in video order
-        all_rows = gather_rows(rows, args.steps * world, nf, device="cuda")
+        all_rows = gather_rows(rows, args.steps * world, nf, device=gather_device)
     sync()
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
     timing = ctx.get_timing()
+    # one more clip with every kernel back to back on one stream: per-kernel durations free of the
+    # interference of the concurrent FFT stream (reported beside the timed-region figures)
+    ctx.set_concurrency(False)
+    ctx.get_timing(reset=True)
+    ctx.set_timing(True)
+    step(0)
+    torch.cuda.synchronize()
+    ctx.set_timing(False)
+    solo = ctx.get_timing(reset=True)
+    ctx.set_concurrency(True)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=gather_device or "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     else:
@@ -173,6 +192,8 @@ def main() -> None:
                 "bound": "hbm", "kernel": dom + " (" + "+".join(k for k in GROUPS[dom] if kt[k]["launches"]) + ")",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_serialized": ab[dom] * nf / (sum(solo["kernels"][k]["ms"] for k in GROUPS[dom]) * 1e-3) / 1e9
+                / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_frame": ab[dom], "frames_per_launch": frames_per_launch,
                 "avg_launch_ms": avg_ms,
                 "note": "the stencil kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~ 99% of SIMD cycles, profiles/), "
@@ -181,6 +202,7 @@ def main() -> None:
                          "frac": path_gbs / HBM_PEAK_GBS},
             },
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in timing["kernels"].items() if v["launches"]},
+            "kernel_ms_per_step_serialized": {k: v["ms"] for k, v in solo["kernels"].items() if v["launches"]},
             "mean_texture_score": float(all_rows[..., 5].mean()),
         }
         if world == 1 and not args.no_cpu_baseline:

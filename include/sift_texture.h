@@ -130,9 +130,12 @@ int stx_pinned_free(stx_ctx* ctx, void* p);
 int stx_memcpy_d2h(stx_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int stx_memcpy_h2d(stx_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 
-/* Frames per internal chunk (0 = choose from the frame size).  Intermediates of one chunk are
- * sized to stay in the 256 MiB Infinity Cache. */
+/* Frames per internal chunk (0 = choose from the frame size: up to 2 GiB of intermediates per
+ * in-flight chunk, two chunks in flight). */
 int stx_set_chunk_frames(stx_ctx* ctx, int frames);
+/* 1 (default): the FFT kernels run on a second stream beside the stencil / hysteresis kernels;
+ * 0: every kernel runs back to back on one stream (clean per-kernel timings). */
+int stx_set_concurrency(stx_ctx* ctx, int enabled);
 int stx_set_timing(stx_ctx* ctx, int enabled);
 int stx_get_timing(stx_ctx* ctx, stx_timing* out, int reset);
 

@@ -20,7 +20,7 @@ EXPORTS = (
     "stx_version", "stx_create", "stx_destroy", "stx_last_error", "stx_backend", "stx_default_params",
     "stx_analyze_batch", "stx_analyze_frames", "stx_analyze_batch_device", "stx_score_summary",
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
-    "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_timing",
+    "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing",
     "stx_get_timing",
 )
 
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
     L.stx_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.stx_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.stx_set_chunk_frames.argtypes = [C.c_void_p, C.c_int]
+    L.stx_set_concurrency.argtypes = [C.c_void_p, C.c_int]
     L.stx_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.stx_get_timing.argtypes = [C.c_void_p, C.POINTER(StxTiming), C.c_int]
     _lib = L

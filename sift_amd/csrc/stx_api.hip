@@ -58,6 +58,7 @@ struct stx_ctx {
     DevBuf codes, plane;
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
+    bool concurrent_fft = true;
     bool timing = false;
     stx_timing tacc;
     std::vector<hipEvent_t> event_pool;
@@ -372,8 +373,8 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // The FFT pair only needs the gray plane: it runs on a second stream, concurrently with the
     // stencil and hysteresis kernels (those saturate the VALUs, the FFTs mostly wait on LDS).
     {
-        hipStream_t sf = c->stream_fft;
-        HIPCHK(c, hipStreamWaitEvent(sf, sl.gray_ready, 0));
+        hipStream_t sf = c->concurrent_fft ? c->stream_fft : s;
+        if (sf != s) HIPCHK(c, hipStreamWaitEvent(sf, sl.gray_ready, 0));
         {
             Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1, sf);
             launch_fft_rows(sf, (const uint8_t*)sl.gray.p, F, g, lay, pr.plan_w, pr.tw_w, (float2*)sl.spec.p);
@@ -384,8 +385,10 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
             launch_fft_cols(sf, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h, (double2*)sl.part.p);
             sp.end();
         }
-        HIPCHK(c, hipEventRecord(sl.fft_done, sf));
-        HIPCHK(c, hipStreamWaitEvent(s, sl.fft_done, 0));
+        if (sf != s) {
+            HIPCHK(c, hipEventRecord(sl.fft_done, sf));
+            HIPCHK(c, hipStreamWaitEvent(s, sl.fft_done, 0));
+        }
     }
     return queue_results(c, sl, pr);
 }
@@ -728,6 +731,11 @@ int stx_memcpy_h2d(stx_ctx* c, void* dst, const void* src, uint64_t bytes) {
 int stx_set_chunk_frames(stx_ctx* c, int frames) {
     if (!c || frames < 0) return STX_ERR_INVALID;
     c->chunk_override = frames;
+    return STX_OK;
+}
+int stx_set_concurrency(stx_ctx* c, int enabled) {
+    if (!c) return STX_ERR_INVALID;
+    c->concurrent_fft = enabled != 0;
     return STX_OK;
 }
 int stx_set_timing(stx_ctx* c, int enabled) {

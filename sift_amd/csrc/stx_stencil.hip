@@ -133,15 +133,17 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     int mag[3][3]; // L1 magnitude rows y-1..y+1, cols x-1..x+1 (0 outside the image)
     int dxc[2], dyc[2];  // gradient at (y,x) and (y+1,x)
 
-    auto load_row = [&](int r, int (&gr)[5], int& hsum, int& rsum, int& d, int& sm) {
-        // r: global row index in [y0-2, y0+TILE_H+1]
-        const uint8_t* rowp = tile + (r - y0 + 2) * LPITCH;
+    // rel: row index relative to ys-2 (0 .. WAVE_ROWS+3); off: 32-bit LDS byte offset of (that
+    // row, column x-2) so that inside an unrolled block the row addresses differ by constants only
+    const uint32_t wave_off = (uint32_t)((wv * WAVE_ROWS) * LPITCH + lc - 2);
+    auto load_row = [&](int rel, uint32_t off, int (&gr)[5], int& hsum, int& rsum, int& d, int& sm) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) gr[j] = rowp[lc + j - 2];
+        for (int j = 0; j < 5; ++j) gr[j] = tile[off + j];
         rsum = gr[1] + gr[2] + gr[3];
         hsum = gr[0] + gr[4] + 4 * (gr[1] + gr[3]) + 6 * gr[2];
         int c3[3];
         if (BORDER) {
+            const int r = ys - 2 + rel;
             const uint8_t* rowc = tile + (iclamp(r, 0, H - 1) - y0 + 2) * LPITCH;
 #pragma unroll
             for (int j = 0; j < 3; ++j) c3[j] = rowc[cc[j]];
@@ -157,7 +159,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     auto sobel_row = [&](int r, int d0, int d1, int d2, int s0, int s2, int (&m)[3], int& gx, int& gy) {
         gx = d0 + 2 * d1 + d2;
         gy = s2 - s0;
-        int mm = abs(gx) + abs(gy);
+        // |gy| + |gx|: s0, s2 are non-negative, so v_sad_u32 gives |s2 - s0| and adds |gx| for free
+        int mm = (int)__usad((uint32_t)s2, (uint32_t)s0, (uint32_t)abs(gx));
         if (BORDER && (r < 0 || r >= H || x >= W)) mm = 0;
         const int rel = r - (ys - 1);
         const int hl = __builtin_amdgcn_readlane(haloL, rel);
@@ -169,10 +172,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 
     // prologue: rows ys-2 .. ys+1
     int dm2, sm2, dm1, sm1;
-    load_row(ys - 2, g[0], hg[0], rs[0], dm2, sm2);
-    load_row(ys - 1, g[1], hg[1], rs[1], dm1, sm1);
-    load_row(ys, g[2], hg[2], rs[2], sd[0], ss[0]);
-    load_row(ys + 1, g[3], hg[3], rs[3], sd[1], ss[1]);
+    load_row(0, wave_off, g[0], hg[0], rs[0], dm2, sm2);
+    load_row(1, wave_off + LPITCH, g[1], hg[1], rs[1], dm1, sm1);
+    load_row(2, wave_off + 2 * LPITCH, g[2], hg[2], rs[2], sd[0], ss[0]);
+    load_row(3, wave_off + 3 * LPITCH, g[3], hg[3], rs[3], sd[1], ss[1]);
     {
         int gx, gy;
         sobel_row(ys - 1, dm2, dm1, sd[0], sm2, ss[0], mag[0], gx, gy);
@@ -212,6 +215,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
         const int yb = ys + blk * BLOCK_ROWS;
         if (BORDER && yb >= H) break;  // wave-uniform: nothing left in the image
+        const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
         // LBP state of this block: per row one byte of SIGN bits (1 = sample below the centre), pushed
         // in sample order 0..7 (so sample s sits at bit 7-s), and four "needs fp64" flags
         // (diagonal sample 2k+1 at bit 3-k).
@@ -221,7 +225,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 #pragma unroll
         for (int i = 0; i < BLOCK_ROWS; ++i) {
             const int y = yb + i;
-            load_row(y + 2, g[4], hg[4], rs[4], sd[2], ss[2]);
+            load_row(blk * BLOCK_ROWS + i + 4, blk_off + (i + 4) * LPITCH, g[4], hg[4], rs[4], sd[2], ss[2]);
             sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
             const bool valid = !BORDER || (xin && (y < H));
             const int c = g[2][2];

@@ -144,6 +144,9 @@ class TextureContext:
     def set_chunk_frames(self, n: int):
         self._check(self.lib.stx_set_chunk_frames(self.handle, n), "stx_set_chunk_frames")
 
+    def set_concurrency(self, on: bool):
+        self._check(self.lib.stx_set_concurrency(self.handle, 1 if on else 0), "stx_set_concurrency")
+
     def set_timing(self, on: bool):
         self._check(self.lib.stx_set_timing(self.handle, 1 if on else 0), "stx_set_timing")
 
