@@ -108,6 +108,18 @@ int stx_analyze_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames,
                              int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
                              stx_metrics* out);
 
+/* Asynchronous form of stx_analyze_batch_device (no counterpart in the reference): queues the work
+ * on the GPU and returns a ticket; stx_wait(ticket) blocks until out[0..n_frames) is filled.  Up to
+ * two submissions may be in flight, so the host part of one clip and the memory-bound gray pass of
+ * the next overlap the compute-bound kernels of the previous one.  n_frames must not exceed
+ * stx_max_async_frames(ctx, h, w); bgr_dev, params and out must stay valid until stx_wait returns.
+ * The synchronous entry points refuse to run while a ticket is outstanding. */
+int stx_submit_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w,
+                            int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
+                            stx_metrics* out, int* ticket);
+int stx_wait(stx_ctx* ctx, int ticket);
+int stx_max_async_frames(stx_ctx* ctx, int h, int w);
+
 /* compute_texture_score's reduction (passive_checker.py:145-156) over n records: mean of the
  * per-frame scores (0.0 when n == 0) and the >= threshold verdict. */
 int stx_score_summary(const stx_metrics* m, int n, double threshold, double* average, int* passed);

@@ -34,6 +34,16 @@ struct TimedSpan {
 
 }  // namespace
 
+// Everything derived from (frame size, parameters) that the kernels of one call need.
+struct Prepared {
+    stx_params p;
+    Geom g;
+    FftLayout lay;
+    FftPlan plan_w, plan_h;
+    float2 *tw_w, *tw_h;
+    LbpOffsets off;
+};
+
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
@@ -43,6 +53,9 @@ struct Slot {
     unsigned int* changed_host = nullptr;  // pinned, one word
     hipEvent_t done = nullptr;
     hipEvent_t gray_ready = nullptr, fft_done = nullptr;
+    bool busy = false;      // an asynchronous submission occupies this slot
+    stx_metrics* async_out = nullptr;
+    Prepared async_pr;
     int passes = 0;  // hysteresis passes queued so far
     int F = 0;
     std::vector<TimedSpan> spans;
@@ -51,8 +64,12 @@ constexpr int N_SLOTS = 2;
 
 struct stx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream_fft = nullptr;  // the FFT kernels run beside the stencil / hysteresis kernels
+    // Three in-order streams shared by all chunks: kernels of one kind from consecutive chunks run
+    // one after the other, kernels of different kinds overlap (the gray pass of chunk i+1 is
+    // memory-bound, the stencil of chunk i VALU-bound, its FFT LDS/latency-bound).
+    hipStream_t stream = nullptr;      // stencil, hysteresis, reductions, result copies, misc
+    hipStream_t stream_pre = nullptr;  // host->device copies and the gray pass
+    hipStream_t stream_fft = nullptr;  // FFT rows + columns
     std::string err;
     Slot slot[N_SLOTS];
     DevBuf codes, plane;
@@ -265,14 +282,6 @@ struct ChunkOpts {
     uint8_t* codes = nullptr;  // device, optional [F][H][W]
 };
 
-struct Prepared {
-    stx_params p;
-    Geom g;
-    FftLayout lay;
-    FftPlan plan_w, plan_h;
-    float2 *tw_w, *tw_h;
-    LbpOffsets off;
-};
 
 int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
     if (!c) return STX_ERR_INVALID;
@@ -291,9 +300,21 @@ int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
     return STX_OK;
 }
 
+bool any_busy(const stx_ctx* c) {
+    for (const Slot& sl : c->slot)
+        if (sl.busy) return true;
+    return false;
+}
+
+void sync_all(stx_ctx* c) {
+    if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre);
+    if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+}
+
 int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g) {
     if (sl.passes + n > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
-    Span sp(c, &sl.spans, STX_K_HYST, n);
+    Span sp(c, &sl.spans, STX_K_HYST, n, c->stream);
     for (int i = 0; i < n; ++i, ++sl.passes)
         launch_hyst_pass(c->stream, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
                          (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
@@ -305,7 +326,7 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
     hipStream_t s = c->stream;
     const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
     {
-        Span sp(c, &sl.spans, STX_K_REDUCE, 1);
+        Span sp(c, &sl.spans, STX_K_REDUCE, 1, s);
         launch_frame_reduce(s, (const uint32_t*)sl.spart.p, lbp81, (const uint32_t*)sl.tiles.p, (const double2*)sl.part.p,
                             pr.lay.parts_per_frame, sl.F, pr.g, (FrameAcc*)sl.acc.p);
         sp.end();
@@ -322,6 +343,7 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
 int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stride, int64_t frame_stride, int F,
                   const Prepared& pr, const ChunkOpts& opts) {
     hipStream_t s = c->stream;
+    hipStream_t spre = c->concurrent_fft ? c->stream_pre : s;
     const Geom& g = pr.g;
     const stx_params& p = pr.p;
     const FftLayout& lay = pr.lay;
@@ -347,23 +369,24 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     sl.F = F;
     sl.passes = 0;
     FrameAcc* acc = (FrameAcc*)sl.acc.p;
-    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
-    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
     {
-        Span sp(c, &sl.spans, STX_K_GRAY, 1);
-        launch_gray(s, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)sl.gray.p);
+        Span sp(c, &sl.spans, STX_K_GRAY, 1, spre);
+        launch_gray(spre, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)sl.gray.p);
         sp.end();
     }
-    HIPCHK(c, hipEventRecord(sl.gray_ready, s));
+    HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
+    if (spre != s) HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));
+    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
+    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
     {
-        Span sp(c, &sl.spans, STX_K_STENCIL, 1);
+        Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
         launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
                        (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr);
         sp.end();
     }
     if (!lbp81) {
-        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 1);
+        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 1, s);
         launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, 0, acc, opts.codes);
         sp.end();
     }
@@ -426,7 +449,7 @@ int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_
         int rc = enqueue_chunk(c, sl, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr, o);
         if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
         if (rc != STX_OK) {
-            (void)hipStreamSynchronize(c->stream);
+            sync_all(c);
             return rc;
         }
         prev_slot = k % N_SLOTS;
@@ -475,7 +498,8 @@ int stx_create(int device_id, stx_ctx** out) {
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
     if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
-    if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking);
     for (int i = 0; i < N_SLOTS && e == hipSuccess; ++i) {
         step = "hipHostMalloc";
         e = hipHostMalloc((void**)&c->slot[i].changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
@@ -500,8 +524,7 @@ int stx_create(int device_id, stx_ctx** out) {
 int stx_destroy(stx_ctx* c) {
     if (!c) return STX_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
+    sync_all(c);
     for (Slot& sl : c->slot) {
         DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
@@ -518,6 +541,7 @@ int stx_destroy(stx_ctx* c) {
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream_fft) (void)hipStreamDestroy(c->stream_fft);
     delete c;
     return STX_OK;
@@ -535,10 +559,55 @@ int stx_analyze_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, i
     if (!bgr_dev || !out) return fail(c, STX_ERR_INVALID, "null pointer");
     if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
         return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
     Prepared pr;
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
     return analyze_device_impl(c, bgr_dev, n_frames, row_stride, frame_stride, pr, out);
+}
+
+int stx_max_async_frames(stx_ctx* c, int h, int w) {
+    if (!c) return STX_ERR_INVALID;
+    stx_params p;
+    stx_default_params(&p);
+    Geom g;
+    if (make_geom(c, h, w, p, &g) != STX_OK) return 0;
+    return pick_chunk(c, g, 1 << 30);
+}
+
+int stx_submit_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                            int64_t frame_stride, const stx_params* params, stx_metrics* out, int* ticket) {
+    if (!c) return STX_ERR_INVALID;
+    if (!ticket || !bgr_dev || !out || n_frames < 1) return fail(c, STX_ERR_INVALID, "bad argument");
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
+    int si = -1;
+    for (int i = 0; i < N_SLOTS; ++i)
+        if (!c->slot[i].busy) { si = i; break; }
+    if (si < 0) return fail(c, STX_ERR_INVALID, "too many submissions in flight: call stx_wait first");
+    Slot& sl = c->slot[si];
+    int rc = prepare(c, h, w, params, &sl.async_pr);
+    if (rc != STX_OK) return rc;
+    if (n_frames > pick_chunk(c, sl.async_pr.g, 1 << 30))
+        return fail(c, STX_ERR_UNSUPPORTED, "n_frames exceeds stx_max_async_frames for this frame size");
+    ChunkOpts o;
+    rc = enqueue_chunk(c, sl, bgr_dev, row_stride, frame_stride, n_frames, sl.async_pr, o);
+    if (rc != STX_OK) { sync_all(c); return rc; }
+    sl.busy = true;
+    sl.async_out = out;
+    *ticket = si;
+    return STX_OK;
+}
+
+int stx_wait(stx_ctx* c, int ticket) {
+    if (!c) return STX_ERR_INVALID;
+    if (ticket < 0 || ticket >= N_SLOTS || !c->slot[ticket].busy) return fail(c, STX_ERR_INVALID, "unknown ticket");
+    Slot& sl = c->slot[ticket];
+    const int rc = finish_chunk(c, sl, sl.async_pr, sl.async_out);
+    sl.busy = false;
+    sl.async_out = nullptr;
+    if (rc != STX_OK) sync_all(c);
+    return rc;
 }
 
 static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* const* list, int n_frames, int h, int w,
@@ -547,6 +616,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
     if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
     if (n_frames == 0) return STX_OK;
     if ((!base && !list) || !out) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
     if (row_stride < (int64_t)3 * w) return fail(c, STX_ERR_INVALID, "row stride smaller than 3*w");
     Prepared pr;
     int rc = prepare(c, h, w, params, &pr);
@@ -564,7 +634,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
         if (dense) {
             rc = STX_OK;
             hipError_t e = hipMemcpyAsync(sl.staging.p, base + (int64_t)f0 * frame_stride, (size_t)F * dframe,
-                                          hipMemcpyHostToDevice, c->stream);
+                                          hipMemcpyHostToDevice, c->concurrent_fft ? c->stream_pre : c->stream);
             if (e != hipSuccess) rc = fail(c, STX_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
         } else {
             for (int i = 0; i < F && rc == STX_OK; ++i) {
@@ -572,7 +642,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
                 if (!src) { rc = fail(c, STX_ERR_INVALID, "null frame pointer"); break; }
                 hipError_t e = hipMemcpy2DAsync((uint8_t*)sl.staging.p + (int64_t)i * dframe, (size_t)dpitch, src,
                                                 (size_t)row_stride, (size_t)3 * w, (size_t)h, hipMemcpyHostToDevice,
-                                                c->stream);
+                                                c->concurrent_fft ? c->stream_pre : c->stream);
                 if (e != hipSuccess) rc = fail(c, STX_ERR_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e));
             }
         }
@@ -585,7 +655,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
         prev_f0 = f0;
     }
     if (rc != STX_OK) {
-        (void)hipStreamSynchronize(c->stream);
+        sync_all(c);
         return rc;
     }
     if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
@@ -644,6 +714,7 @@ int stx_debug_planes(stx_ctx* c, const uint8_t* bgr, int h, int w, int64_t row_s
     if (!c) return STX_ERR_INVALID;
     if (!bgr) return fail(c, STX_ERR_INVALID, "null pointer");
     if (row_stride < (int64_t)3 * w) return fail(c, STX_ERR_INVALID, "row stride smaller than 3*w");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
     Prepared pr;
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
@@ -653,7 +724,7 @@ int stx_debug_planes(stx_ctx* c, const uint8_t* bgr, int h, int w, int64_t row_s
     if ((rc = ensure(c, c->codes, (size_t)h * w)) != STX_OK) return rc;
     if ((rc = ensure(c, c->plane, (size_t)h * w)) != STX_OK) return rc;
     HIPCHK(c, hipMemcpy2DAsync(sl.staging.p, (size_t)dpitch, bgr, (size_t)row_stride, (size_t)3 * w, (size_t)h,
-                               hipMemcpyHostToDevice, c->stream));
+                               hipMemcpyHostToDevice, c->concurrent_fft ? c->stream_pre : c->stream));
     ChunkOpts o;
     o.codes = (uint8_t*)c->codes.p;
     if ((rc = enqueue_chunk(c, sl, (const uint8_t*)sl.staging.p, dpitch, dpitch * h, 1, pr, o)) != STX_OK) return rc;

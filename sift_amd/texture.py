@@ -109,6 +109,21 @@ class TextureContext:
         self._check(rc, "stx_analyze_batch_device")
         return out
 
+    def submit_device(self, dev_ptr: int, n: int, h: int, w: int, out, params: Optional[StxParams] = None) -> int:
+        """Queue the analysis of n device-resident frames; returns a ticket for wait().  `out` (a ctypes
+        array of StxMetrics) and `params` must stay alive until wait() returns."""
+        t = C.c_int(-1)
+        rc = self.lib.stx_submit_batch_device(self.handle, dev_ptr, n, h, w, 3 * w, 3 * w * h,
+                                              C.byref(params) if params is not None else None, out, C.byref(t))
+        self._check(rc, "stx_submit_batch_device")
+        return t.value
+
+    def wait(self, ticket: int):
+        self._check(self.lib.stx_wait(self.handle, ticket), "stx_wait")
+
+    def max_async_frames(self, h: int, w: int) -> int:
+        return int(self.lib.stx_max_async_frames(self.handle, h, w))
+
     def synth_device(self, dev_ptr: int, kind: int, seed: int, video: int, frame0: int, n: int, h: int, w: int):
         self._check(self.lib.stx_synth_device(self.handle, dev_ptr, kind, seed, video, frame0, n, h, w), "stx_synth_device")
 

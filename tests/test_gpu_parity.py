@@ -219,3 +219,36 @@ def test_two_detectors_one_process():
     f = synth_frame("natural", SEED, 40, 0, 64, 64)
     assert a.analyze_frame(f) == b.analyze_frame(f)
     assert a.threshold == 0.6
+
+
+def test_async_submit_wait(ctx, coracle):
+    import ctypes as C
+    from sift_amd._lib import StxError, StxMetrics
+    h, w, n = 96, 160, 6
+    nbytes = n * h * w * 3
+    devs = [ctx.device_alloc(nbytes) for _ in range(2)]
+    try:
+        for v, d in enumerate(devs):
+            ctx.synth_device(d, KIND_ID["natural"], SEED + 7, v, 0, n, h, w)
+        want = [ctx.analyze_device(d, n, h, w) for d in devs]
+        assert ctx.max_async_frames(h, w) >= n
+        outs = [(StxMetrics * n)() for _ in range(2)]
+        for round_ in range(3):
+            t0 = ctx.submit_device(devs[0], n, h, w, outs[0])
+            t1 = ctx.submit_device(devs[1], n, h, w, outs[1])
+            assert t0 != t1
+            with pytest.raises(StxError):
+                ctx.submit_device(devs[0], n, h, w, outs[0])  # only two in flight
+            with pytest.raises(StxError):
+                ctx.analyze_device(devs[0], n, h, w)          # blocking calls refuse to interleave
+            ctx.wait(t1)
+            ctx.wait(t0)
+            with pytest.raises(StxError):
+                ctx.wait(t0)
+            for o, wv in zip(outs, want):
+                assert bytes(o) == bytes(wv)[: C.sizeof(o)]
+        m = coracle.analyze_frame(synth_clip("natural", SEED + 7, 1, n, h, w)[2])
+        _check_record(outs[1][2], m)
+    finally:
+        for d in devs:
+            ctx.device_free(d)
