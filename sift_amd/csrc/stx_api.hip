@@ -234,12 +234,12 @@ int make_geom(stx_ctx* c, int h, int w, const stx_params& p, Geom* g) {
     if (h < 1 || w < 1) return fail(c, STX_ERR_INVALID, "frame height and width must be >= 1");
     if (h > STX_MAX_DIM || w > STX_MAX_DIM) return fail(c, STX_ERR_UNSUPPORTED, "frame larger than 8192 in one dimension");
     g->H = h; g->W = w;
-    g->gpitch = ((w + 63) / 64) * 64 + 64;
+    g->gpitch = ((w + 127) / 128) * 128 + 64;
     g->grows = h + 4;
-    g->wpr = (w + 63) / 64;
-    g->tiles_x = g->wpr;
+    g->tiles_x = (w + 127) / 128;
     g->tiles_y = (h + 127) / 128;
-    g->htiles_y = (h + 63) / 64;
+    g->bm_words = (h + 63) / 64;
+    g->bm_tiles = (w + 63) / 64;
     g->fh = p.fft_h > 0 ? p.fft_h : h;
     g->fw = p.fft_w > 0 ? p.fft_w : w;
     if (g->fh > h || g->fw > w) return fail(c, STX_ERR_INVALID, "fft crop larger than the frame");
@@ -259,7 +259,7 @@ int check_params(stx_ctx* c, const stx_params& p) {
 }
 
 size_t per_frame_workspace(const Geom& g) {
-    return (size_t)g.grows * g.gpitch + 2 * (size_t)g.H * g.wpr * 8 + (size_t)g.fh * (g.fwh + 15) * sizeof(float2);
+    return (size_t)g.grows * g.gpitch + 2 * (size_t)g.W * g.bm_words * 8 + (size_t)g.fh * (g.fwh + 15) * sizeof(float2);
 }
 
 int pick_chunk(const stx_ctx* c, const Geom& g, int n_frames) {
@@ -349,13 +349,13 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     const FftLayout& lay = pr.lay;
     int rc;
     if ((rc = ensure(c, sl.gray, (size_t)F * g.grows * g.gpitch)) != STX_OK) return rc;
-    const size_t bm = (size_t)F * g.H * g.wpr * sizeof(unsigned long long);
+    const size_t bm = (size_t)F * g.W * g.bm_words * sizeof(unsigned long long);
     if ((rc = ensure(c, sl.strong, bm)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.cand, bm)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.tiles, (size_t)F * g.htiles_y * g.wpr * sizeof(uint32_t))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.tflag, (size_t)2 * F * g.htiles_y * g.wpr)) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.tiles, (size_t)F * g.bm_tiles * g.bm_words * sizeof(uint32_t))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.tflag, (size_t)2 * F * g.bm_tiles * g.bm_words)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.spart, (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;

@@ -2,11 +2,14 @@
 // on one-bit-per-pixel maps: "strong" grows into every "candidate" pixel that is
 // 8-connected to it, transitively.
 //
-// One wave owns a 64x64 pixel tile: lane = row, one 64-bit word = that row's 64 pixels
-// (maps are stored [frame][word column][row], so a tile's 64 words are contiguous).
-// Vertical neighbours come from the adjacent lanes, horizontal ones from shifts, and a
-// strong bit floods a whole horizontal run of candidates in O(1) with a carry chain:
-// adding the seed bits to the run mask ripples a carry to the end of each run.  The tile
+// The maps run down the image columns: a "line" is one pixel column, a 64-bit word holds 64
+// vertically adjacent pixels of it, and the maps are stored [frame][word][line], so the 64
+// words of a 64x64 tile are contiguous.  (8-connectivity does not care which axis the words
+// run along; the stencil kernel produces its bits column by column.)  One wave owns a tile:
+// lane = line.  Neighbours across lines come from the adjacent lanes, neighbours along a
+// line from shifts, and a strong bit floods a whole run of candidates along its line in O(1)
+// with a carry chain: adding the seed bits to the run mask ripples a carry to the end of
+// each run.  The tile
 // iterates to its local fix-point, then the host launches further passes until a pass
 // changes nothing anywhere (stale reads of a neighbouring tile's words are harmless: the
 // map only ever grows, and the last pass re-checks every tile against final neighbours).
@@ -26,63 +29,64 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
     return up | dn | x;
 }
 
-// tflag: [2][frames][htiles_y][wpr] bytes, one per tile and pass parity: "this tile changed in
+// tflag: [2][frames][ntiles][nwords] bytes, one per tile and pass parity: "this tile changed in
 // that pass".  From pass 1 on a tile is revisited only if it or one of its eight neighbours
-// changed in the previous pass.
+// changed in the previous pass.  nlines = image width, nwords = words per line, ntiles =
+// 64-line tiles across the image.
 __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
-                                                       const unsigned long long* __restrict__ cand, int H, int wpr,
-                                                       int htiles_y, unsigned int* changed, int pass,
+                                                       const unsigned long long* __restrict__ cand, int nlines,
+                                                       int nwords, int ntiles, unsigned int* changed, int pass,
                                                        uint32_t* __restrict__ tile_count, uint8_t* tflag,
                                                        int64_t tflag_half) {
     if (pass > 0 && changed[pass - 1] == 0) return;
-    const int frame = blockIdx.z, ty = blockIdx.y, wx = blockIdx.x;
+    const int frame = blockIdx.z, tl = blockIdx.y, wx = blockIdx.x;
     const int lane = threadIdx.x;
-    const int64_t tbase = (int64_t)frame * htiles_y * wpr;
+    const int64_t tbase = (int64_t)frame * ntiles * nwords;
     uint8_t* fl_cur = tflag + (int64_t)(pass & 1) * tflag_half + tbase;
     if (pass > 0) {
         const uint8_t* fl_prev = tflag + (int64_t)((pass - 1) & 1) * tflag_half + tbase;
         // lanes 0..8 look at the 3x3 tile neighbourhood
         int f = 0;
         if (lane < 9) {
-            const int ny = ty + lane / 3 - 1, nx = wx + lane % 3 - 1;
-            if (ny >= 0 && ny < htiles_y && nx >= 0 && nx < wpr) f = fl_prev[ny * wpr + nx];
+            const int nl = tl + lane / 3 - 1, nx = wx + lane % 3 - 1;
+            if (nl >= 0 && nl < ntiles && nx >= 0 && nx < nwords) f = fl_prev[nl * nwords + nx];
         }
         if (!__any(f != 0)) {
-            if (lane == 0) fl_cur[ty * wpr + wx] = 0;
+            if (lane == 0) fl_cur[tl * nwords + wx] = 0;
             return;
         }
     }
-    const int y = ty * 64 + lane;
-    // bitmaps are stored [frame][word column][row]: the 64 rows of a tile are contiguous
-    unsigned long long* sb = strong + ((int64_t)frame * wpr + wx) * H;
-    const unsigned long long* cb = cand + ((int64_t)frame * wpr + wx) * H;
-    const bool rowin = y < H;
-    const bool hasl = wx > 0, hasr = wx + 1 < wpr;
+    const int ln = tl * 64 + lane;
+    // maps are stored [frame][word][line]: the 64 lines of a tile are contiguous
+    unsigned long long* sb = strong + ((int64_t)frame * nwords + wx) * nlines;
+    const unsigned long long* cb = cand + ((int64_t)frame * nwords + wx) * nlines;
+    const bool lin = ln < nlines;
+    const bool hasl = wx > 0, hasr = wx + 1 < nwords;  // previous / next word along the lines
     unsigned long long S = 0, C = 0, Lw = 0, Rw = 0;
-    if (rowin) {
-        S = sb[y];
-        C = cb[y];
-        if (hasl) Lw = sb[y - H];
-        if (hasr) Rw = sb[y + H];
+    if (lin) {
+        S = sb[ln];
+        C = cb[ln];
+        if (hasl) Lw = sb[ln - nlines];
+        if (hasr) Rw = sb[ln + nlines];
     }
-    // halo rows above and below the tile (own word and its two neighbours)
+    // halo lines before and after the tile (own word and its two neighbours)
     unsigned long long To = 0, Tl = 0, Tr = 0, Bo = 0, Bl = 0, Br = 0;
-    const int yt = ty * 64 - 1, yb = ty * 64 + 64;
-    if (yt >= 0) {
-        To = sb[yt];
-        if (hasl) Tl = sb[yt - H];
-        if (hasr) Tr = sb[yt + H];
+    const int lt = tl * 64 - 1, lb = tl * 64 + 64;
+    if (lt >= 0) {
+        To = sb[lt];
+        if (hasl) Tl = sb[lt - nlines];
+        if (hasr) Tr = sb[lt + nlines];
     }
-    if (yb < H) {
-        Bo = sb[yb];
-        if (hasl) Bl = sb[yb - H];
-        if (hasr) Br = sb[yb + H];
+    if (lb < nlines) {
+        Bo = sb[lb];
+        if (hasl) Bl = sb[lb - nlines];
+        if (hasr) Br = sb[lb + nlines];
     }
     unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
     unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
     if (lane == 0) { upL = Tl; upR = Tr; }
     if (lane == 63) { dnL = Bl; dnR = Br; }
-    // pixels of the neighbouring word columns that touch this word's first / last pixel
+    // pixels of the neighbouring words that touch this word's first / last pixel
     const unsigned long long carry = ((upL | Lw | dnL) >> 63) | (((upR | Rw | dnR) & 1ull) << 63);
 
     const unsigned long long orig = S;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
     } while (any);
 
     const bool ch = S != orig;
-    if (ch) sb[y] = S;
+    if (ch) sb[ln] = S;
     const bool tile_changed = __any(ch);
     uint32_t cnt = __popcll(S);
 #pragma unroll
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __res
     if (lane == 0) {
         // a flag, not a count: every writer stores the same value, so a plain store is enough
         if (tile_changed) changed[pass] = 1u;
-        fl_cur[ty * wpr + wx] = tile_changed ? 1 : 0;
-        tile_count[tbase + ty * wpr + wx] = cnt;
+        fl_cur[tl * nwords + wx] = tile_changed ? 1 : 0;
+        tile_count[tbase + tl * nwords + wx] = cnt;
     }
 }
 
@@ -166,31 +170,30 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
 }
 
 __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long long* __restrict__ strong, int H, int W,
-                                                           int wpr, uint8_t* __restrict__ edges) {
+                                                           uint8_t* __restrict__ edges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)H * W) return;
     const int y = (int)(i / W), x = (int)(i % W);
-    edges[i] = ((strong[(int64_t)(x >> 6) * H + y] >> (x & 63)) & 1ull) ? 255 : 0;
+    edges[i] = ((strong[(int64_t)(y >> 6) * W + x] >> (y & 63)) & 1ull) ? 255 : 0;
 }
 
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
-    dim3 grid(g.wpr, g.htiles_y, n_frames);
-    const int64_t half = (int64_t)n_frames * g.htiles_y * g.wpr;
-    hipLaunchKernelGGL(hyst_pass_kernel, grid, dim3(64), 0, s, strong, cand, g.H, g.wpr, g.htiles_y, changed, pass,
+    dim3 grid(g.bm_words, g.bm_tiles, n_frames);
+    const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
+    hipLaunchKernelGGL(hyst_pass_kernel, grid, dim3(64), 0, s, strong, cand, g.W, g.bm_words, g.bm_tiles, changed, pass,
                        tile_count, tflag, half);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
                          const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc) {
     hipLaunchKernelGGL(frame_reduce_kernel, dim3(n_frames), dim3(256), 0, s, spart, g.tiles_x * g.tiles_y,
-                       lbp_from_tiles ? 1 : 0, tile_count, g.htiles_y * g.wpr, fpart, nfparts, acc);
+                       lbp_from_tiles ? 1 : 0, tile_count, g.bm_tiles * g.bm_words, fpart, nfparts, acc);
 }
 
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges) {
     const int64_t n = (int64_t)g.H * g.W;
-    hipLaunchKernelGGL(edges_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, strong, g.H, g.W, g.wpr,
-                       edges);
+    hipLaunchKernelGGL(edges_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, strong, g.H, g.W, edges);
 }
 
 }  // namespace stx

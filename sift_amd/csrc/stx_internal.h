@@ -24,12 +24,14 @@ struct FrameAcc {
 // Geometry of one chunk of equally sized frames in the workspace.
 struct Geom {
     int H, W;        // frame size
-    int gpitch;      // bytes per row of the padded gray plane: roundup(W,64)+64
+    int gpitch;      // bytes per row of the padded gray plane: roundup(W,128)+64
     int grows;       // rows of the padded gray plane: H+4 (two reflected rows above and below)
-    int wpr;         // 64-pixel bitmap words per row: ceil(W/64)
-    int tiles_x;     // ceil(W/64)
-    int tiles_y;     // ceil(H/128) stencil tiles
-    int htiles_y;    // ceil(H/64) hysteresis tiles
+    int tiles_x;     // ceil(W/128) stencil tiles
+    int tiles_y;     // ceil(H/128)
+    // Canny bitmaps run down the columns: one 64-bit word = 64 vertically adjacent pixels of one column,
+    // stored [frame][bm_words][W].  A hysteresis tile is 64 columns x 64 rows.
+    int bm_words;    // ceil(H/64) words per column
+    int bm_tiles;    // ceil(W/64) hysteresis tiles across
     int fh, fw;      // FFT extent
     int foy, fox;    // FFT crop origin in the frame
     int fwh;         // fw/2+1 half-spectrum columns
@@ -64,7 +66,7 @@ void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
                         int halo, FrameAcc* acc, uint8_t* codes_out);
 
 // One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
-// changed nothing.  changed[] must be zeroed before pass 0.
+// changed nothing.  changed[] must be zeroed before pass 0.  tile_count: [frame][bm_tiles][bm_words].
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

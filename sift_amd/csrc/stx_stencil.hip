@@ -4,28 +4,87 @@
 //   * 5x5 Gaussian residual |gray - blur| -> sum             (:111-113)
 //   * Sobel + L1 magnitude + non-maximum suppression + double threshold
 //     -> two bitmaps (strong, candidate), one bit per pixel  (:116, first half of Canny)
-// A 256-thread workgroup owns a 64x128 pixel tile; each wave owns 32 rows, each lane one
-// column, and marches down its column with the 5x5 neighbourhood held in registers.  The
-// wave's 64 lanes are 64 consecutive pixels, so __ballot() of a per-pixel predicate IS the
-// 64-bit bitmap word of that row.
+// A 256-thread workgroup owns a 128x128 pixel tile; each wave owns 32 rows and marches down
+// them.  A lane owns TWO adjacent pixel columns and keeps them as packed 16-bit pairs, so the
+// integer stencils run on v_pk_*_u16 / v_sad_u16 / v_dot2_u32_u16 at two pixels per
+// instruction.  Every intermediate fits 16 bits: the 5x5 binomial sum is at most 255*256,
+// Sobel components at most 1020, the L1 magnitude at most 2040.
 //
-// LBP bits are those of the fp64 arithmetic scikit-image performs (every operation rounded
-// separately, in its order); an fp32 evaluation with a proven error margin settles the clear
-// cases and only near-ties run the fp64 sequence.  This file must be compiled with
-// -ffp-contract=off.
+// The Canny bits of a pixel column are collected down the strip (one 32-bit word per column
+// and strip), which is the layout the hysteresis kernel works on: [frame][64-row word][column].
+//
+// LBP: the four axis samples are the neighbouring pixels themselves; the four diagonal samples
+// are bilinear.  Their sign against the centre is first decided in 16.16 fixed point (two
+// v_dot2_u32_u16 per sample); the rounded weights put that value within about 140/65536 of the exact
+// one (the bound is computed from the actual rounding errors at launch), so anything further
+// than that from the centre has the sign scikit-image's fp64 arithmetic produces.  Pixels with a closer sample are queued and re-evaluated per lane in the
+// order-exact fp64 sequence.  This file must be compiled with -ffp-contract=off.
 #include "stx_internal.h"
 
 namespace stx {
 
 #pragma clang fp contract(off)
 
-constexpr int TILE_W = 64;
-constexpr int WAVE_ROWS = 32;       // rows marched by one wave
-constexpr int BLOCK_ROWS = 8;       // rows per unrolled block
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+
+constexpr int TILE_W = 128;        // 64 lanes x 2 pixels
+constexpr int WAVE_ROWS = 32;      // rows marched by one wave
+constexpr int BLOCK_ROWS = 8;      // rows per unrolled block
 constexpr int TILE_H = 4 * WAVE_ROWS;
 constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+TILE_H+1
-constexpr int LPITCH = 72;         // bytes: columns x0-4 .. x0+67
+constexpr int LPITCH = TILE_W + 8; // bytes: columns x0-4 .. x0+131
 constexpr int LDW = LPITCH / 4;
+constexpr int LUT_INVALID = 256;       // histogram table slot that adds nothing
+
+// ---- packed 16-bit helpers (operands travel as plain 32-bit words) ----
+__device__ __forceinline__ us2 asU(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ ss2 asS(uint32_t v) { return __builtin_bit_cast(ss2, v); }
+__device__ __forceinline__ uint32_t word(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t word(ss2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return word(asU(a) + asU(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return word(asS(a) - asS(b)); }
+template <int K>
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t c) {  // a*K + c in one v_pk_mad_u16 (K is an inline constant)
+    static_assert(K >= 0 && K <= 64, "inline constant");
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a) {
+    const us2 k = {(unsigned short)K, (unsigned short)K};
+    return word(asU(a) * k);
+}
+template <int N>
+__device__ __forceinline__ uint32_t pk_shr(uint32_t a) {
+    const us2 n = {(unsigned short)N, (unsigned short)N};
+    return word(asU(a) >> n);
+}
+__device__ __forceinline__ uint32_t pk_sign_mask(uint32_t a) {  // 0xFFFF where the element is negative
+    // opaque to the optimiser on purpose: seen through, the mask selects below turn into per-half compares
+    uint32_t d;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_abs(uint32_t a) { return word(__builtin_elementwise_max(asS(a), -asS(a))); }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+    return word(__builtin_elementwise_sub_sat(asU(a), asU(b)));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return word(__builtin_elementwise_min(asU(a), asU(b))); }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// |a.lo - b.lo| + |a.hi - b.hi| + acc on unsigned 16-bit halves
+__device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc) {
+    uint32_t d;
+    asm("v_sad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t b, uint32_t acc) {
+    return __builtin_amdgcn_udot2(asU(a), asU(b), acc, false);
+}
+// sign bit of v appended below acc: (acc << 1) | (v >> 31)
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v) { return __builtin_amdgcn_alignbit(acc, v, 31); }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -54,41 +113,53 @@ __device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, double bl, dou
 
 struct StencilArgs {
     const uint8_t* gray;
-    int H, W, gpitch, grows, wpr;
-    int low, high;
+    int H, W, gpitch, grows, bm_words;
+    uint32_t low2, high2;                   // thresholds, clamped to [-1, 4095], in both halves
     double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
-    uint32_t* part;  // [frame][tiles][16]: 10 LBP bins, hp sum, hp sum of squares, |gray-blur| sum, gray sum
-    unsigned long long* strong;
-    unsigned long long* cand;
-    uint8_t* codes;  // optional per-pixel LBP codes [frame][H][W]
+    // 16.16 weights of the diagonal samples 1,3,5,7: (left, right) pixel of the upper and lower cell row
+    uint32_t w1t, w1b, w3t, w3b, w5t, w5b, w7t, w7b;
+    uint32_t margin;   // bound on |fixed-point sample - exact sample| in 1/65536 gray levels, plus a guard
+    uint32_t* part;    // [frame][tiles][16]: 10 LBP bins, hp sum, hp sum of squares, |gray-blur| sum, gray sum
+    uint32_t* strong;  // [frame][bm_words][W] 64-bit words, written as 32-bit halves (one per 32-row strip)
+    uint32_t* cand;
+    uint8_t* codes;    // optional per-pixel LBP codes [frame][H][W]
 };
 
-// sign bit of v appended below acc: (acc << 1) | (v >> 31)
-__device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v) { return __builtin_amdgcn_alignbit(acc, v, 31); }
+// byte selectors for v_perm_b32 over {hi source, lo source}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = zero
+constexpr uint32_t SEL_PAIR = 0x0c010c00;   // (b0, b1) of the low source
+constexpr uint32_t SEL_CROSS = 0x0c040c01;  // (b1 of the low source, b0 of the high source)
+
+// Everything derived from one image row for this lane's two columns x, x+1.
+struct RowD {
+    uint32_t hg;            // horizontal [1 4 6 4 1] (reflected border)
+    uint32_t rs;            // horizontal 3-sum (reflected border)
+    uint32_t zm1, z0, zp1;  // pixel pairs (x-1,x) (x,x+1) (x+1,x+2), zero outside the image (LBP view)
+    uint32_t d, sm;         // horizontal Sobel difference and smoothing (replicated border, Canny view)
+};
 
 template <bool BORDER, bool DO_LBP, bool CODES>
-__device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, int frame, int x0, int y0, int lane,
-                                      int wv, uint32_t* red /*[16] per wave*/) {
+__device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const unsigned long long* lut,
+                                      int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
-    const int x = x0 + lane;
+    const int x = x0 + 2 * lane;  // this lane's pixels: x (low half) and x+1 (high half)
     const int ys = y0 + wv * WAVE_ROWS;
-    const int lc = lane + GRAY_XOFF;  // LDS column of pixel x
-    const bool xin = !BORDER || x < W;
+    const uint32_t vm = BORDER ? ((x < W ? 0xFFFFu : 0u) | (x + 1 < W ? 0xFFFF0000u : 0u)) : 0xFFFFFFFFu;
 
-    // LDS column indices of x-1, x, x+1 in the Canny (replicated border) view
-    int cc[3];
+    // Border strips build the Canny (replicate) and LBP (zero) views with per-lane byte selectors over
+    // the six window bytes x-2 .. x+3.
+    uint32_t selC[3] = {0, 0, 0}, selZ[3] = {0, 0, 0};
+    if (BORDER) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cc[j] = BORDER ? (iclamp(x + j - 1, 0, W - 1) - x0 + GRAY_XOFF) : (lc + j - 1);
-
-    // per-column LBP weights
-    double dcP = 0, dcN = 0;
-    if (DO_LBP) {
-        const double cfp = (double)x + a.cp_pos;
-        dcP = cfp - floor(cfp);
-        const double cfn = (double)x + a.cp_neg;
-        dcN = cfn - floor(cfn);
+        for (int k = 0; k < 3; ++k) {
+            const int e0 = x + k - 1, e1 = e0 + 1;
+            const int c0 = iclamp(iclamp(e0, 0, W - 1) - (x - 2), 0, 5);
+            const int c1 = iclamp(iclamp(e1, 0, W - 1) - (x - 2), 0, 5);
+            selC[k] = (uint32_t)c0 | 0x0c00u | ((uint32_t)c1 << 16) | 0x0c000000u;
+            const int z0 = (e0 >= 0 && e0 < W) ? e0 - (x - 2) : 0x0c;
+            const int z1 = (e1 >= 0 && e1 < W) ? e1 - (x - 2) : 0x0c;
+            selZ[k] = (uint32_t)z0 | 0x0c00u | ((uint32_t)z1 << 16) | 0x0c000000u;
+        }
     }
-    const float wcP = (float)dcP, wcN = (float)dcN;
 
     // Sobel magnitude of the Canny view at any pixel of the strip's neighbourhood (dynamic LDS
     // indices; used for the two halo columns only)
@@ -107,309 +178,302 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         const int gy = (v[2][0] - v[0][0]) + 2 * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2]);
         return abs(gx) + abs(gy);
     };
-    // The magnitudes left of lane 0 and right of lane 63 belong to the neighbouring strips: lane l
+    // The magnitudes left of lane 0 and right of lane 63 belong to the neighbouring tiles: lane l
     // computes them once for row ys-1+l, the marching loop fetches them with a lane read.
-    int haloL = 0, haloR = 0;
+    int haloL16 = 0, haloR = 0;
     if (lane < WAVE_ROWS + 2) {
-        haloL = mag_at(ys - 1 + lane, x0 - 1);
-        haloR = mag_at(ys - 1 + lane, x0 + TILE_W);
+        haloL16 = mag_at(ys - 1 + lane, x0 - 1) << 16;  // lands in the high half: the pair (x0-2, x0-1)
+        haloR = mag_at(ys - 1 + lane, x0 + TILE_W);     // low half of the pair (x0+128, x0+129)
     }
 
-    // fp32 row weights of the LBP samples above / below row ys+lane (lanes 0..31)
-    int rowWN = 0, rowWP = 0;
-    if (DO_LBP) {
-        const double rfn = (double)(ys + lane) + a.rp_neg;
-        rowWN = __float_as_int((float)(rfn - floor(rfn)));
-        const double rfp = (double)(ys + lane) + a.rp_pos;
-        rowWP = __float_as_int((float)(rfp - floor(rfp)));
-    }
-
-    // sliding state
-    int g[5][5];   // reflected view, rows y-2..y+2, cols x-2..x+2
-    int hg[5];     // horizontal [1 4 6 4 1] of those rows
-    int rs[5];     // g[r][1]+g[r][2]+g[r][3]
-    int sd[3];     // horizontal Sobel difference at x of rows y, y+1, y+2 (Canny view)
-    int ss[3];     // horizontal Sobel smoothing at x of the same rows
-    int mag[3][3]; // L1 magnitude rows y-1..y+1, cols x-1..x+1 (0 outside the image)
-    int dxc[2], dyc[2];  // gradient at (y,x) and (y+1,x)
-
-    // rel: row index relative to ys-2 (0 .. WAVE_ROWS+3); off: 32-bit LDS byte offset of (that
-    // row, column x-2) so that inside an unrolled block the row addresses differ by constants only
-    const uint32_t wave_off = (uint32_t)((wv * WAVE_ROWS) * LPITCH + lc - 2);
-    auto load_row = [&](int rel, uint32_t off, int (&gr)[5], int& hsum, int& rsum, int& d, int& sm) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) gr[j] = tile[off + j];
-        rsum = gr[1] + gr[2] + gr[3];
-        hsum = gr[0] + gr[4] + 4 * (gr[1] + gr[3]) + 6 * gr[2];
-        int c3[3];
-        if (BORDER) {
-            const int r = ys - 2 + rel;
-            const uint8_t* rowc = tile + (iclamp(r, 0, H - 1) - y0 + 2) * LPITCH;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c3[j] = rowc[cc[j]];
+    // rel: row index relative to ys-2 (0 .. WAVE_ROWS+3); off: LDS byte offset of (that row, column x-2)
+    const uint32_t wave_off = (uint32_t)((wv * WAVE_ROWS) * LPITCH + 2 * lane + 2);
+    auto load_row = [&](int rel, uint32_t off, RowD& o) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(tile + off);
+        const uint32_t A = p[0], B = p[1], C = p[2];  // bytes (x-2,x-1) (x,x+1) (x+2,x+3)
+        const uint32_t tm2 = perm(0, A, SEL_PAIR), tm1 = perm(B, A, SEL_CROSS), t0 = perm(0, B, SEL_PAIR),
+                       tp1 = perm(C, B, SEL_CROSS), tp2 = perm(0, C, SEL_PAIR);
+        const uint32_t s1 = pk_add(tm1, tp1);
+        o.hg = pk_mad<6>(t0, pk_mad<4>(s1, pk_add(tm2, tp2)));
+        o.rs = pk_add(s1, t0);
+        if (!BORDER) {
+            o.zm1 = tm1; o.z0 = t0; o.zp1 = tp1;
+            o.d = pk_sub(tp1, tm1);
+            o.sm = pk_mad<2>(t0, s1);
         } else {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c3[j] = gr[j + 1];
-        }
-        d = c3[2] - c3[0];
-        sm = c3[0] + 2 * c3[1] + c3[2];
-    };
-    // gradient and magnitudes of row r (rows r-1, r, r+1 are d0/s0, d1, d2/s2); the neighbours'
-    // magnitudes come from the adjacent lanes
-    auto sobel_row = [&](int r, int d0, int d1, int d2, int s0, int s2, int (&m)[3], int& gx, int& gy) {
-        gx = d0 + 2 * d1 + d2;
-        gy = s2 - s0;
-        // |gy| + |gx|: s0, s2 are non-negative, so v_sad_u32 gives |s2 - s0| and adds |gx| for free
-        int mm = (int)__usad((uint32_t)s2, (uint32_t)s0, (uint32_t)abs(gx));
-        if (BORDER && (r < 0 || r >= H || x >= W)) mm = 0;
-        const int rel = r - (ys - 1);
-        const int hl = __builtin_amdgcn_readlane(haloL, rel);
-        const int hr = __builtin_amdgcn_readlane(haloR, rel);
-        m[0] = __builtin_amdgcn_update_dpp(hl, mm, 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 keeps hl
-        m[1] = mm;
-        m[2] = __builtin_amdgcn_update_dpp(hr, mm, 0x130, 0xf, 0xf, false);  // wave_shl:1, lane 63 keeps hr
-    };
-
-    // prologue: rows ys-2 .. ys+1
-    int dm2, sm2, dm1, sm1;
-    load_row(0, wave_off, g[0], hg[0], rs[0], dm2, sm2);
-    load_row(1, wave_off + LPITCH, g[1], hg[1], rs[1], dm1, sm1);
-    load_row(2, wave_off + 2 * LPITCH, g[2], hg[2], rs[2], sd[0], ss[0]);
-    load_row(3, wave_off + 3 * LPITCH, g[3], hg[3], rs[3], sd[1], ss[1]);
-    {
-        int gx, gy;
-        sobel_row(ys - 1, dm2, dm1, sd[0], sm2, ss[0], mag[0], gx, gy);
-        sobel_row(ys, dm1, sd[0], sd[1], sm1, ss[1], mag[1], dxc[0], dyc[0]);
-    }
-
-    // LBP row state, sliding with the window: the zero-padded 3 neighbours of rows y-1..y+1, the centre
-    // column as float, and the row-wise interpolations of the left cell (columns x-1,x; weight dcN)
-    // and the right cell (columns x,x+1; weight dcP).  Each image row is converted and interpolated once
-    // and serves the three centre rows that touch it.
-    int nm[3][3];
-    float fcs[3], lLs[3], lRs[3];
-    auto lbp_row = [&](int yy, const int (&gr)[5], int (&nrow)[3], float& fc, float& l_left, float& l_right) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            int v = gr[q + 1];
-            if (BORDER) {
-                const int xx = x + q - 1;
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;
+            const int ry = ys - 2 + rel;
+            const bool rin = ry >= 0 && ry < H;
+            const uint32_t AB = A | (B << 16);
+            o.zm1 = rin ? perm(C, AB, selZ[0]) : 0u;
+            o.z0 = rin ? perm(C, AB, selZ[1]) : 0u;
+            o.zp1 = rin ? perm(C, AB, selZ[2]) : 0u;
+            uint32_t cAB = AB, cC = C;
+            if (!rin) {  // wave-uniform: the Canny view repeats the first / last image row
+                const uint16_t* q = reinterpret_cast<const uint16_t*>(tile + (iclamp(ry, 0, H - 1) - y0 + 2) * LPITCH +
+                                                                      2 * lane + 2);
+                cAB = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
+                cC = q[2];
             }
-            nrow[q] = v;
+            const uint32_t cm1 = perm(cC, cAB, selC[0]), c0 = perm(cC, cAB, selC[1]), cp1 = perm(cC, cAB, selC[2]);
+            o.d = pk_sub(cp1, cm1);
+            o.sm = pk_mad<2>(c0, pk_add(cm1, cp1));
         }
-        const float f0 = (float)nrow[0], f1 = (float)nrow[1], f2 = (float)nrow[2];
-        fc = f1;
-        l_left = __builtin_fmaf(wcN, f1 - f0, f0);
-        l_right = __builtin_fmaf(wcP, f2 - f1, f1);
     };
-    if (DO_LBP) {
-        lbp_row(ys - 1, g[1], nm[0], fcs[0], lLs[0], lRs[0]);
-        lbp_row(ys, g[2], nm[1], fcs[1], lLs[1], lRs[1]);
+
+    // Gradient and L1 magnitude of row r from the Sobel partials of rows r-1, r, r+1, and the same
+    // magnitudes seen from the left / right neighbour columns: ML = (x-1, x), MR = (x+1, x+2).
+    struct MagRow { uint32_t ML, M, MR, ax, ay, sxy; };
+    auto mag_row = [&](int r, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t s0, uint32_t s2, MagRow& o) {
+        const uint32_t gx = word(asS(d1) + asS(d1) + (asS(d0) + asS(d2)));
+        const uint32_t gy = pk_sub(s2, s0);
+        o.ax = pk_abs(gx);
+        o.ay = pk_abs(gy);
+        o.sxy = gx ^ gy;
+        uint32_t m = pk_add(o.ax, o.ay);
+        if (BORDER) m &= (r >= 0 && r < H) ? vm : 0u;
+        const int rel = r - (ys - 1);
+        const int hl = __builtin_amdgcn_readlane(haloL16, rel);
+        const int hr = __builtin_amdgcn_readlane(haloR, rel);
+        const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(hl, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(hr, (int)m, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        o.M = m;
+        o.ML = __builtin_amdgcn_alignbit(m, mp, 16);
+        o.MR = __builtin_amdgcn_alignbit(mn, m, 16);
+    };
+
+    // sliding state: rows y-2..y+2 of the binomial row sums, y-1..y+2 of the rest
+    RowD rw[5];   // rw[j] = row y-2+j
+    MagRow mg[3]; // rows y-1, y, y+1
+    {
+        load_row(0, wave_off, rw[0]);
+        load_row(1, wave_off + LPITCH, rw[1]);
+        load_row(2, wave_off + 2 * LPITCH, rw[2]);
+        load_row(3, wave_off + 3 * LPITCH, rw[3]);
+        mag_row(ys - 1, rw[0].d, rw[1].d, rw[2].d, rw[0].sm, rw[2].sm, mg[0]);
+        mag_row(ys, rw[1].d, rw[2].d, rw[3].d, rw[1].sm, rw[3].sm, mg[1]);
     }
 
-    unsigned long long hist6 = 0;  // ten 6-bit counters (at most 32 pixels per lane)
+    unsigned long long hist_lo = 0, hist_hi = 0;  // ten 6-bit counters per pixel column (at most 32 rows each)
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
+    uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, newest row lowest, per half
+    uint32_t accS0 = 0, accC0 = 0;    // rows 0..15 of the strip
 
 #pragma unroll 1
     for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
         const int yb = ys + blk * BLOCK_ROWS;
-        if (BORDER && yb >= H) break;  // wave-uniform: nothing left in the image
-        const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
-        // LBP state of this block: per row one byte of SIGN bits (1 = sample below the centre), pushed
-        // in sample order 0..7 (so sample s sits at bit 7-s), and four "needs fp64" flags
-        // (diagonal sample 2k+1 at bit 3-k).
-        unsigned long long sign64 = 0;
-        uint32_t pend = 0;
-        unsigned long long bm_s = 0, bm_c = 0;
-#pragma unroll
-        for (int i = 0; i < BLOCK_ROWS; ++i) {
-            const int y = yb + i;
-            load_row(blk * BLOCK_ROWS + i + 4, blk_off + (i + 4) * LPITCH, g[4], hg[4], rs[4], sd[2], ss[2]);
-            sobel_row(y + 1, sd[0], sd[1], sd[2], ss[0], ss[2], mag[2], dxc[1], dyc[1]);
-            const bool valid = !BORDER || (xin && (y < H));
-            const int c = g[2][2];
-
-            // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
-            {
-                const int v = iclamp(9 * c - (rs[1] + rs[2] + rs[3]), 0, 255);
-                if (valid) { hp_s += v; hp_q += v * v; gr_s += c; }
-            }
-            // ---- Gaussian residual
-            {
-                const int S = hg[0] + hg[4] + 4 * (hg[1] + hg[3]) + 6 * hg[2];
-                const int blur = (S + 128) >> 8;
-                if (valid) ad_s += abs(c - blur);
-            }
-            // ---- LBP (P=8, R=1), first stage
-            if (DO_LBP) {
-                lbp_row(y + 1, g[3], nm[2], fcs[2], lLs[2], lRs[2]);  // rows y-1 and y slid in earlier
-                // the row weights are wave-uniform: lane l computed those of row ys+l before the loop
-                const float wrN = __int_as_float(__builtin_amdgcn_readlane(rowWN, blk * BLOCK_ROWS + i));
-                const float wrP = __int_as_float(__builtin_amdgcn_readlane(rowWP, blk * BLOCK_ROWS + i));
-                const int (&n)[3][3] = nm;
-                const float (&lL)[3] = lLs;
-                const float (&lR)[3] = lRs;
-                const int ce = n[1][1];
-                // Diagonal samples in fp32: the value is within 2e-4 of the exact bilinear value and the
-                // fp64 sequence within 1e-12, so |value - centre| >= 1e-3 settles the sign; anything
-                // closer is queued for the order-exact fp64 evaluation after this block.
-                const float fc = fcs[1];
-                const float d1 = __builtin_fmaf(wrN, lR[1] - lR[0], lR[0]) - fc;  // sample 1 (-.7,+.7)
-                const float d3 = __builtin_fmaf(wrN, lL[1] - lL[0], lL[0]) - fc;  // sample 3 (-.7,-.7)
-                const float d5 = __builtin_fmaf(wrP, lL[2] - lL[1], lL[1]) - fc;  // sample 5 (+.7,-.7)
-                const float d7 = __builtin_fmaf(wrP, lR[2] - lR[1], lR[1]) - fc;  // sample 7 (+.7,+.7)
-                // The axis samples have integer coordinates: the interpolation returns the pixel itself.
-                uint32_t sg = 0;
-                sg = push_sign(sg, (uint32_t)(n[1][2] - ce));      // sample 0 (0,+1)
-                sg = push_sign(sg, __float_as_uint(d1));
-                sg = push_sign(sg, (uint32_t)(n[0][1] - ce));      // sample 2 (-1,0)
-                sg = push_sign(sg, __float_as_uint(d3));
-                sg = push_sign(sg, (uint32_t)(n[1][0] - ce));      // sample 4 (0,-1)
-                sg = push_sign(sg, __float_as_uint(d5));
-                sg = push_sign(sg, (uint32_t)(n[2][1] - ce));      // sample 6 (+1,0)
-                sg = push_sign(sg, __float_as_uint(d7));
-                uint32_t un = 0;
-                un = push_sign(un, __float_as_uint(__builtin_fabsf(d1) - 1e-3f));
-                un = push_sign(un, __float_as_uint(__builtin_fabsf(d3) - 1e-3f));
-                un = push_sign(un, __float_as_uint(__builtin_fabsf(d5) - 1e-3f));
-                un = push_sign(un, __float_as_uint(__builtin_fabsf(d7) - 1e-3f));
-                if (!valid) un = 0;
-                sign64 |= (unsigned long long)sg << (8 * i);
-                pend |= un << (4 * i);
-            }
-            // ---- Canny non-maximum suppression + double threshold, branch-free: pick the two
-            // neighbours along the quantised gradient direction, then two compares.  The second
-            // neighbour is compared with >= for horizontal / vertical gradients and with > for
-            // diagonal ones; for integers m >= b is m > b-1.
-            {
-                const int m = mag[1][1];
-                unsigned long long sb = 0, cb = 0;
-                // most rows of a smooth image have no pixel above the low threshold: one wave-uniform
-                // test skips the whole selection for them
-                if (__any(m > a.low && valid)) {
-                    const int xs = dxc[0], ysg = dyc[0];
-                    const int ax = abs(xs), ay = abs(ysg) << 15;
-                    const int tg22x = ax * 13573;
-                    const int tg67x = tg22x + (ax << 16);
-                    const bool horiz = ay < tg22x;
-                    const bool vert = ay > tg67x;
-                    const bool opp = (xs ^ ysg) < 0;
-                    int na = opp ? mag[0][2] : mag[0][0];
-                    int nb = opp ? mag[2][0] : mag[2][2];
-                    na = vert ? mag[0][1] : na;
-                    nb = vert ? mag[2][1] - 1 : nb;
-                    na = horiz ? mag[1][0] : na;
-                    nb = horiz ? mag[1][2] - 1 : nb;
-                    const bool keep = (m > na) && (m > nb) && valid;
-                    sb = __ballot(keep && m > a.high);
-                    cb = __ballot(keep && m > a.low);
-                }
-                // park the two bitmap words of row i in lane i; lanes 0..7 store them after the block
-                if (lane == i) { bm_s = sb; bm_c = cb; }
-            }
-            // ---- slide down one row
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) g[r][j] = g[r + 1][j];
-                hg[r] = hg[r + 1];
-                rs[r] = rs[r + 1];
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                sd[r] = sd[r + 1];
-                ss[r] = ss[r + 1];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) mag[r][j] = mag[r + 1][j];
-            }
-            dxc[0] = dxc[1];
-            dyc[0] = dyc[1];
-            if (DO_LBP) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) nm[r][q] = nm[r + 1][q];
-                    fcs[r] = fcs[r + 1];
-                    lLs[r] = lLs[r + 1];
-                    lRs[r] = lRs[r + 1];
-                }
-            }
-        }
-        if (lane < BLOCK_ROWS && (!BORDER || yb + lane < H)) {
-            const int64_t wi = ((int64_t)frame * a.wpr + (x0 >> 6)) * H + yb + lane;  // [frame][word column][row]
-            a.strong[wi] = bm_s;
-            a.cand[wi] = bm_c;
-        }
-        if (DO_LBP) {
-            // ---- LBP second stage: near-ties, one (row, sample) per lane and iteration, in the fp64
-            // arithmetic of skimage's bilinear_interpolation (operands re-read from the LDS tile)
-            auto lbp_px = [&](int yy, int xx) -> double {
-                if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
-                return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
-            };
-            while (__any(pend != 0)) {
-                if (pend != 0) {
-                    const int b = __ffs(pend) - 1;
-                    pend &= pend - 1;
-                    const int i = b >> 2, k = 3 - (b & 3);  // diagonal sample 2k+1 of row i
-                    const int y = yb + i;
-                    const int r0 = (k >= 2) ? y : y - 1;             // upper row of the 2x2 cell
-                    const int c0 = (k == 1 || k == 2) ? x - 1 : x;  // left column of the cell
-                    const double rf = (double)y + ((k >= 2) ? a.rp_pos : a.rp_neg);
-                    const double dr = rf - floor(rf);
-                    const double dc = (k == 1 || k == 2) ? dcN : dcP;
-                    const uint32_t bit = lbp_bit(lbp_px(r0, c0), lbp_px(r0, c0 + 1), lbp_px(r0 + 1, c0),
-                                                 lbp_px(r0 + 1, c0 + 1), dr, dc, lbp_px(y, x));
-                    const int pos = 8 * i + 7 - (2 * k + 1);
-                    sign64 = (sign64 & ~(1ull << pos)) | ((unsigned long long)(bit ^ 1u) << pos);
-                }
-            }
-            // ---- codes and histogram of this block (bit order is reversed, which changes neither
-            // the number of 0/1 transitions between consecutive samples nor the number of ones)
+        if (BORDER && yb >= H) {  // wave-uniform: nothing left in the image, the remaining bits are zero
+            accS = pk_mul<256>(accS);
+            accC = pk_mul<256>(accC);
+        } else {
+            const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
+            // LBP state of this block.  Signs are stored as "1 = sample below the centre".
+            uint32_t sgA[BLOCK_ROWS];         // axis samples 0,2,4,6 at bits 15..12 / 31..28 (two pixels)
+            uint32_t sgd_lo = 0, sgd_hi = 0;  // diagonal samples 1,3,5,7: one nibble per row, row 0 highest
+            uint32_t pend = 0;                // near-tie flags, pushed low pixel then high pixel per row
 #pragma unroll
             for (int i = 0; i < BLOCK_ROWS; ++i) {
                 const int y = yb + i;
-                const uint32_t bits = ~(uint32_t)(sign64 >> (8 * i)) & 0xFFu;
-                const int changes = __popc((bits ^ (bits >> 1)) & 0x7Fu);
-                const int code = (changes <= 2) ? __popc(bits) : 9;
-                if (!BORDER || (xin && y < H)) {
-                    hist6 += 1ull << (6 * code);
-                    if (CODES) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)code;
+                load_row(blk * BLOCK_ROWS + i + 4, blk_off + (i + 4) * LPITCH, rw[4]);
+                mag_row(y + 1, rw[2].d, rw[3].d, rw[4].d, rw[2].sm, rw[4].sm, mg[2]);
+                const uint32_t vmy = BORDER ? ((y < H) ? vm : 0u) : 0xFFFFFFFFu;
+                const uint32_t c2 = rw[2].z0;  // the two centre pixels (zero where invalid)
+
+                // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
+                {
+                    const uint32_t sum3 = pk_add(pk_add(rw[1].rs, rw[2].rs), rw[3].rs);
+                    const uint32_t v = pk_min(pk_sub_sat(pk_mul<9>(c2), sum3), 0x00FF00FFu);
+                    hp_s = sad_u16(v, 0, hp_s);
+                    hp_q = dot2(v, v, hp_q);
+                    gr_s = sad_u16(c2, 0, gr_s);
+                }
+                // ---- Gaussian residual
+                {
+                    const uint32_t S = pk_mad<6>(rw[2].hg, pk_mad<4>(pk_add(rw[1].hg, rw[3].hg), pk_add(rw[0].hg, rw[4].hg)));
+                    uint32_t blur = pk_shr<8>(pk_add(S, 0x00800080u));
+                    if (BORDER) blur &= vmy;
+                    ad_s = sad_u16(c2, blur, ad_s);
+                }
+                // ---- LBP (P=8, R=1), first stage
+                if (DO_LBP) {
+                    // axis samples: the neighbours themselves, both pixels at once
+                    const uint32_t r0 = pk_sub(rw[2].zp1, c2);  // sample 0 (0,+1)
+                    const uint32_t r2 = pk_sub(rw[1].z0, c2);   // sample 2 (-1,0)
+                    const uint32_t r4 = pk_sub(rw[2].zm1, c2);  // sample 4 (0,-1)
+                    const uint32_t r6 = pk_sub(rw[3].z0, c2);   // sample 6 (+1,0)
+                    sgA[i] = bfi(0x80008000u, r0, bfi(0x40004000u, r2 >> 1, bfi(0x20002000u, r4 >> 2, r6 >> 3)));
+                    // diagonal samples in 16.16 fixed point, offset by the margin: t = (sample - centre) + margin.
+                    // t < 0 or t > 2*margin settles the sign (and then sign(t) is the sign); otherwise queue.
+                    const uint32_t init_lo = a.margin - (c2 << 16);
+                    const uint32_t init_hi = a.margin - (c2 & 0xFFFF0000u);
+                    uint32_t tmin;
+                    {
+                        const uint32_t t1 = dot2(rw[1].z0, a.w1t, dot2(rw[2].z0, a.w1b, init_lo));    // (-.7,+.7)
+                        const uint32_t t3 = dot2(rw[1].zm1, a.w3t, dot2(rw[2].zm1, a.w3b, init_lo));  // (-.7,-.7)
+                        const uint32_t t5 = dot2(rw[2].zm1, a.w5t, dot2(rw[3].zm1, a.w5b, init_lo));  // (+.7,-.7)
+                        const uint32_t t7 = dot2(rw[2].z0, a.w7t, dot2(rw[3].z0, a.w7b, init_lo));    // (+.7,+.7)
+                        sgd_lo = push_sign(push_sign(push_sign(push_sign(sgd_lo, t1), t3), t5), t7);
+                        tmin = min(min(t1, t3), min(t5, t7));
+                        if (BORDER) tmin = (vmy & 0xFFFFu) ? tmin : 0xFFFFFFFFu;
+                        pend = (pend << 1) | (tmin <= 2 * a.margin ? 1u : 0u);
+                    }
+                    {
+                        const uint32_t t1 = dot2(rw[1].zp1, a.w1t, dot2(rw[2].zp1, a.w1b, init_hi));
+                        const uint32_t t3 = dot2(rw[1].z0, a.w3t, dot2(rw[2].z0, a.w3b, init_hi));
+                        const uint32_t t5 = dot2(rw[2].z0, a.w5t, dot2(rw[3].z0, a.w5b, init_hi));
+                        const uint32_t t7 = dot2(rw[2].zp1, a.w7t, dot2(rw[3].zp1, a.w7b, init_hi));
+                        sgd_hi = push_sign(push_sign(push_sign(push_sign(sgd_hi, t1), t3), t5), t7);
+                        tmin = min(min(t1, t3), min(t5, t7));
+                        if (BORDER) tmin = (vmy >> 16) ? tmin : 0xFFFFFFFFu;
+                        pend = (pend << 1) | (tmin <= 2 * a.margin ? 1u : 0u);
+                    }
+                }
+                // ---- Canny non-maximum suppression + double threshold on both pixels at once.  The sign
+                // bit of each 16-bit difference is the predicate; masks select the two neighbours along the
+                // quantised gradient direction.  tan(22.5 deg) = 13573/2^15 and |gx| <= 1020, so
+                // floor(|gx|*13573/2^15) = (|gx|*53 + (|gx|*5 >> 8)) >> 7 stays inside 16 bits.
+                {
+                    const uint32_t m = mg[1].M;
+                    const uint32_t nz = pk_sub(a.low2, m);  // negative where m > low
+                    uint32_t ks = 0, kc = 0;
+                    if (__any((nz & 0x80008000u) != 0)) {
+                        const uint32_t ax = mg[1].ax, ay = mg[1].ay;
+                        const uint32_t q22 = pk_shr<7>(pk_mad<53>(ax, pk_shr<8>(pk_mul<5>(ax))));
+                        const uint32_t nothoriz = pk_sign_mask(pk_sub(q22, ay));              // |gy| > tan22 |gx|
+                        const uint32_t vert = pk_sign_mask(pk_sub(pk_mad<2>(ax, q22), ay));   // |gy| > tan67 |gx|
+                        const uint32_t opp = pk_sign_mask(mg[1].sxy);
+                        uint32_t na = bfi(opp, mg[0].MR, mg[0].ML);
+                        uint32_t nb = bfi(opp, mg[2].ML, mg[2].MR);
+                        na = bfi(vert, mg[0].M, na);
+                        nb = bfi(vert, mg[2].M, nb);
+                        na = bfi(nothoriz, na, mg[1].ML);
+                        nb = bfi(nothoriz, nb, mg[1].MR);
+                        // the second neighbour is compared with >= for horizontal / vertical gradients:
+                        // m >= nb is m > nb - 1
+                        nb = pk_add(nb, bfi(nothoriz, vert, 0xFFFFFFFFu));
+                        kc = pk_sub(na, m) & pk_sub(nb, m) & nz;
+                        ks = kc & pk_sub(a.high2, m);
+                    }
+                    accC = pk_mad<2>(accC, pk_shr<15>(kc));
+                    accS = pk_mad<2>(accS, pk_shr<15>(ks));
+                }
+                // ---- slide down one row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r] = rw[r + 1];
+                mg[0] = mg[1];
+                mg[1] = mg[2];
+            }
+            if (DO_LBP) {
+                // ---- LBP second stage: queued pixels, one per lane and iteration, all four diagonal samples
+                // in the fp64 arithmetic of skimage's bilinear_interpolation (operands re-read from the tile)
+                auto lbp_px = [&](int yy, int xx) -> double {
+                    if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
+                    return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+                };
+                while (__any(pend != 0)) {
+                    if (pend != 0) {
+                        const int slot = 2 * BLOCK_ROWS - __ffs(pend);  // 0 = row 0 low pixel, 1 = row 0 high pixel, ...
+                        pend &= pend - 1;
+                        const int i = slot >> 1, e = slot & 1;
+                        const int y = yb + i, xx = x + e;
+                        double n[3][3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) n[r][q] = lbp_px(y - 1 + r, xx - 1 + q);
+                        const double rfn = (double)y + a.rp_neg, rfp = (double)y + a.rp_pos;
+                        const double drN = rfn - floor(rfn), drP = rfp - floor(rfp);
+                        const double cfp = (double)xx + a.cp_pos, cfn = (double)xx + a.cp_neg;
+                        const double dcP = cfp - floor(cfp), dcN = cfn - floor(cfn);
+                        const double ce = n[1][1];
+                        const uint32_t b1 = lbp_bit(n[0][1], n[0][2], n[1][1], n[1][2], drN, dcP, ce);
+                        const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
+                        const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
+                        const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
+                        const uint32_t nib = (((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu) << (4 * (BLOCK_ROWS - 1 - i));
+                        const uint32_t keep = ~(0xFu << (4 * (BLOCK_ROWS - 1 - i)));
+                        if (e) sgd_hi = (sgd_hi & keep) | nib;
+                        else sgd_lo = (sgd_lo & keep) | nib;
+                    }
+                }
+                // ---- codes and histogram of this block: the eight sign bits index a table of 1 << 6*code
+#pragma unroll
+                for (int i = 0; i < BLOCK_ROWS; ++i) {
+                    const int y = yb + i;
+                    const int sh = 4 * (BLOCK_ROWS - 1 - i);
+                    uint32_t il = ((sgA[i] >> 12) & 0xFu) | (((sgd_lo >> sh) & 0xFu) << 4);
+                    uint32_t ih = ((sgA[i] >> 28) & 0xFu) | (((sgd_hi >> sh) & 0xFu) << 4);
+                    if (BORDER) {
+                        il = (y < H && x < W) ? il : (uint32_t)LUT_INVALID;
+                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)LUT_INVALID;
+                    }
+                    const unsigned long long el = lut[il], eh = lut[ih];
+                    hist_lo += el;
+                    hist_hi += eh;
+                    if (CODES) {
+                        if (el) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)((__ffsll(el) - 1) / 6);
+                        if (eh) a.codes[((int64_t)frame * H + y) * W + x + 1] = (uint8_t)((__ffsll(eh) - 1) / 6);
+                    }
                 }
             }
         }
+        if (blk == 1) {
+            accS0 = accS; accC0 = accC;
+            accS = 0; accC = 0;
+        }
     }
 
-    // ---- wave reduction: 10 histogram bins (two words of five 12-bit fields), four sums
-    unsigned long long lo = 0, hi = 0;
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-        lo |= ((hist6 >> (6 * b)) & 63ull) << (12 * b);
-        hi |= ((hist6 >> (6 * (b + 5))) & 63ull) << (12 * b);
+    // ---- the strip's Canny bits: row r of the strip at bit r of a 32-bit word per pixel column
+    {
+        const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * W;
+        const int half = (ys >> 5) & 1;
+        if (x < W) {
+            const int64_t wi = (wbase + x) * 2 + half;
+            a.strong[wi] = __brev((accS0 << 16) | (accS & 0xFFFFu));
+            a.cand[wi] = __brev((accC0 << 16) | (accC & 0xFFFFu));
+        }
+        if (x + 1 < W) {
+            const int64_t wi = (wbase + x + 1) * 2 + half;
+            a.strong[wi] = __brev((accS0 & 0xFFFF0000u) | (accS >> 16));
+            a.cand[wi] = __brev((accC0 & 0xFFFF0000u) | (accC >> 16));
+        }
     }
-    lo = wave_sum_u64s(lo);
-    hi = wave_sum_u64s(hi);
-    hp_s = wave_sum_u32(hp_s);
-    hp_q = wave_sum_u32(hp_q);
-    ad_s = wave_sum_u32(ad_s);
-    gr_s = wave_sum_u32(gr_s);
+
+    // ---- wave reduction: 10 histogram bins as 16-bit fields (a strip holds 4096 pixels), four sums
+    unsigned long long w0 = 0, w1 = 0, w2 = 0;
+    {
+        auto bin = [&](int b) -> unsigned long long { return ((hist_lo >> (6 * b)) & 63ull) + ((hist_hi >> (6 * b)) & 63ull); };
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            w0 |= bin(b) << (16 * b);
+            w1 |= bin(b + 4) << (16 * b);
+        }
+        w2 = bin(8) | (bin(9) << 16) | ((unsigned long long)hp_q << 32);
+    }
+    // high-pass sum, residual sum, gray sum: at most 64*255 per lane, 21-bit fields hold the wave total
+    unsigned long long w3 = (unsigned long long)hp_s | ((unsigned long long)ad_s << 21) | ((unsigned long long)gr_s << 42);
+    w0 = wave_sum_u64s(w0);
+    w1 = wave_sum_u64s(w1);
+    w2 = wave_sum_u64s(w2);
+    w3 = wave_sum_u64s(w3);
     if (lane == 0) {
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            red[b] = (uint32_t)((lo >> (12 * b)) & 0xFFFull);
-            red[b + 5] = (uint32_t)((hi >> (12 * b)) & 0xFFFull);
+        for (int b = 0; b < 4; ++b) {
+            red[b] = (uint32_t)((w0 >> (16 * b)) & 0xFFFFull);
+            red[b + 4] = (uint32_t)((w1 >> (16 * b)) & 0xFFFFull);
         }
-        red[10] = hp_s;
-        red[11] = hp_q;
-        red[12] = ad_s;
-        red[13] = gr_s;
+        red[8] = (uint32_t)(w2 & 0xFFFFull);
+        red[9] = (uint32_t)((w2 >> 16) & 0xFFFFull);
+        red[10] = (uint32_t)(w3 & 0x1FFFFFull);
+        red[11] = (uint32_t)(w2 >> 32);
+        red[12] = (uint32_t)((w3 >> 21) & 0x1FFFFFull);
+        red[13] = (uint32_t)(w3 >> 42);
     }
 }
 
 template <bool DO_LBP, bool CODES>
 __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
     __shared__ uint32_t tile[LROWS * LDW];
+    __shared__ unsigned long long lut[LUT_INVALID + 2];
     __shared__ uint32_t red[4][16];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * TILE_W;
@@ -424,6 +488,21 @@ __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
         gy = gy < a.grows ? gy : a.grows - 1;
         tile[i] = *reinterpret_cast<const uint32_t*>(gp + (int64_t)gy * a.gpitch + x0 + col * 4);
     }
+    if (DO_LBP) {
+        // Histogram table.  Index: bits 3..0 = signs of samples 0,2,4,6, bits 7..4 = signs of samples 1,3,5,7
+        // (1 = sample below the centre).  Uniform patterns (at most two 0/1 changes along samples 0..7)
+        // get their number of ones, everything else P+1 = 9.
+        uint32_t pat = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sa = ((uint32_t)tid >> (3 - k)) & 1u, sd = ((uint32_t)tid >> (7 - k)) & 1u;
+            pat |= ((sa ^ 1u) << (2 * k)) | ((sd ^ 1u) << (2 * k + 1));  // LBP bit of sample s at bit s
+        }
+        const int changes = __popc((pat ^ (pat >> 1)) & 0x7Fu);
+        const int code = (changes <= 2) ? __popc(pat) : 9;
+        lut[tid] = 1ull << (6 * code);
+        if (tid < 2) lut[LUT_INVALID + tid] = 0;
+    }
     if (tid < 64) red[tid >> 4][tid & 15] = 0;
     __syncthreads();
 
@@ -433,9 +512,21 @@ __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, frame, x0, y0, lane, wv, red[wv]);
+    } else if ((ys >> 6) < a.bm_words) {
+        // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
+        const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
+        const int half = (ys >> 5) & 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int xx = x0 + 2 * lane + e;
+            if (xx < a.W) {
+                a.strong[(wbase + xx) * 2 + half] = 0;
+                a.cand[(wbase + xx) * 2 + half] = 0;
+            }
+        }
     }
     __syncthreads();
     // per-tile partial sums, one slot per tile: no atomics, summed in a fixed order later
@@ -446,16 +537,50 @@ __global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
     }
 }
 
+// 16.16 weights (left, right) of one cell row: row weight wr times (1-dc, dc).  The rounding errors
+// are added to epos / eneg (sum of the positive ones, sum of the negative ones' magnitudes).
+static uint32_t weight_pair(double wr, double dc, double* epos, double* eneg) {
+    const double wl = 65536.0 * wr * (1.0 - dc), wh = 65536.0 * wr * dc;
+    const long long l = llround(wl), r = llround(wh);
+    const double el = (double)l - wl, er = (double)r - wh;
+    *epos += (el > 0 ? el : 0) + (er > 0 ? er : 0);
+    *eneg += (el < 0 ? -el : 0) + (er < 0 ? -er : 0);
+    return (uint32_t)l | ((uint32_t)r << 16);
+}
+static double frac(double v) { return v - floor(v); }
+
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out) {
     StencilArgs a;
     a.gray = gray;
-    a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.wpr = g.wpr;
-    a.low = low; a.high = high;
+    a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.bm_words = g.bm_words;
+    // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound
+    const uint32_t lo = (uint32_t)(low < -1 ? -1 : (low > 4095 ? 4095 : low)) & 0xFFFFu;
+    const uint32_t hi = (uint32_t)(high < -1 ? -1 : (high > 4095 ? 4095 : high)) & 0xFFFFu;
+    a.low2 = lo | (lo << 16);
+    a.high2 = hi | (hi << 16);
     // (P=8,R=1): samples 1,3 sit above the centre (rp<0), 5,7 below; 1,7 right (cp>0), 3,5 left
     a.rp_neg = off.rp[1]; a.rp_pos = off.rp[5]; a.cp_pos = off.cp[1]; a.cp_neg = off.cp[3];
-    a.part = part; a.strong = strong; a.cand = cand; a.codes = codes_out;
+    const double drN = frac(a.rp_neg), drP = frac(a.rp_pos), dcP = frac(a.cp_pos), dcN = frac(a.cp_neg);
+    // With pixels in [0,255] the fixed-point sample is off by at most 255 * (sum of the one-sided weight
+    // errors); the guard of 2 covers the 1e-12 spread of the per-pixel fp64 weights and fp64 rounding.
+    double worst = 0.0;
+    auto sample_weights = [&](double dr, double dc, uint32_t* top, uint32_t* bottom) {
+        double ep = 0.0, en = 0.0;
+        *top = weight_pair(1.0 - dr, dc, &ep, &en);
+        *bottom = weight_pair(dr, dc, &ep, &en);
+        worst = fmax(worst, 255.0 * fmax(ep, en));
+    };
+    sample_weights(drN, dcP, &a.w1t, &a.w1b);
+    sample_weights(drN, dcN, &a.w3t, &a.w3b);
+    sample_weights(drP, dcN, &a.w5t, &a.w5b);
+    sample_weights(drP, dcP, &a.w7t, &a.w7b);
+    a.margin = (uint32_t)ceil(worst) + 2u;
+    a.part = part;
+    a.strong = reinterpret_cast<uint32_t*>(strong);
+    a.cand = reinterpret_cast<uint32_t*>(cand);
+    a.codes = codes_out;
     dim3 grid(g.tiles_x, g.tiles_y, n_frames);
     if (!do_lbp81)
         hipLaunchKernelGGL((stencil_kernel<false, false>), grid, dim3(256), 0, s, a);
