@@ -66,6 +66,17 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
     return __builtin_bit_cast(float2, r);
 }
 
+// Same with a compile-time constant factor: the constant travels in a scalar register pair (one
+// scalar operand per instruction is allowed), not in a vector pair that has to be filled with moves.
+__device__ __forceinline__ float2 cmulf_const(float2 a, float kre, float kim) {
+    const v2f va = __builtin_bit_cast(v2f, a);
+    const v2f vb = {kre, kim};
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(va), "s"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(va), "s"(vb), "v"(t));
+    return __builtin_bit_cast(float2, r);
+}
+
 // v * exp(-2 pi i m / R) for compile-time-foldable m
 template <int R>
 __device__ __forceinline__ float2 mul_tw(float2 v, int m, const Tw<R>& tw) {
@@ -73,7 +84,7 @@ __device__ __forceinline__ float2 mul_tw(float2 v, int m, const Tw<R>& tw) {
     if (4 * m == R) return make_float2(v.y, -v.x);
     if (2 * m == R) return make_float2(-v.x, -v.y);
     if (4 * m == 3 * R) return make_float2(-v.y, v.x);
-    return cmulf(v, make_float2(tw.re[m], tw.im[m]));
+    return cmulf_const(v, tw.re[m], tw.im[m]);
 }
 
 // ---------------------------------------------------------------- register DFTs
@@ -273,6 +284,119 @@ __device__ __forceinline__ void transform(float2* buf, const float2* twg, int t)
     transform_to<P>(buf, twg, t, st);
 }
 
+// ---------------------------------------------------------------- row transform: fused first and last pass
+// First pass straight from global memory.  Butterfly j of a radix-R0 first pass reads x[j + r*M0],
+// M0 = N/R0.  When M0 is 64, 128 or 256 a lane that loads B = M0/64 adjacent bytes at byte offset
+// B*(t + 64 r), r = 0..R0-1, holds every input of the B butterflies j = B*t .. B*t+B-1, so the signal
+// never has to be staged in LDS: R0 narrow loads per image row and lane, each a contiguous
+// 64*B-byte segment across the wave.
+template <class P>
+struct Direct {
+    static constexpr int M0 = P::N / P::R0;
+    static constexpr int B = M0 / 64;
+    static constexpr bool ok = P::LPT == 64 && M0 % 64 == 0 && (B == 1 || B == 2 || B == 4);
+};
+
+template <int B>
+__device__ __forceinline__ uint32_t load_bytes(const uint8_t* p, int idx) {
+    if constexpr (B == 1) return p[idx];
+    else if constexpr (B == 2) return reinterpret_cast<const uint16_t*>(p)[idx];
+    else return reinterpret_cast<const uint32_t*>(p)[idx];
+}
+
+// ra / rb: the loads of the two image rows packed into one complex signal (row a real, row b imaginary)
+template <class P>
+__device__ __forceinline__ void pass0_direct(float2* __restrict__ buf, const uint32_t (&ra)[P::R0],
+                                             const uint32_t (&rb)[P::R0], int t) {
+    constexpr int R = P::R0, B = Direct<P>::B;
+    float2 out[B * R];
+#pragma unroll
+    for (int e = 0; e < B; ++e) {
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[r] = make_float2((float)((ra[r] >> (8 * e)) & 255u) - 128.0f, (float)((rb[r] >> (8 * e)) & 255u) - 128.0f);
+        Dft<R>::run(v);
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[e * R + r] = v[r];
+    }
+    // butterfly j writes its outputs to j*R0 .. j*R0+R0-1: B*R0 consecutive elements per lane
+    const int base = B * t * R;
+    if constexpr (!P::SWZ && (B * R) % 2 == 0) {
+        float4* d4 = reinterpret_cast<float4*>(buf + base);
+#pragma unroll
+        for (int q = 0; q < B * R / 2; ++q) d4[q] = make_float4(out[2 * q].x, out[2 * q].y, out[2 * q + 1].x, out[2 * q + 1].y);
+    } else {
+#pragma unroll
+        for (int q = 0; q < B * R; ++q) buf[pad<P::SWZ>(base + q)] = out[q];
+    }
+    wave_sync();
+}
+
+// Last pass fused with the split of the packed transform.  Z[k] and Z[N-k] come out of butterflies j and
+// M-j (M = N/R) of the last pass, so a lane that runs both holds every conjugate pair it needs:
+//   A[k] = (Z[k] + conj Z[N-k]) / 2,   B[k] = (Z[k] - conj Z[N-k]) / 2i
+// go from registers to global memory, and the pass neither writes LDS nor is re-read by a split loop.
+// Work item i = 1..(M-1)/2 runs butterflies i and M-i.  Butterflies 0 and (M even) M/2 hold their own
+// partners; item 0 runs those two.  emit(k, Z[k], Z[N-k]) is called once for every k in 0..N/2.
+template <class P, int R, class Emit>
+__device__ __forceinline__ void last_pass_pairs(const float2* __restrict__ buf, const float2* __restrict__ twg, int t,
+                                                Emit& emit) {
+    constexpr int N = P::N, M = N / R;
+    constexpr bool EVEN = (M % 2) == 0;
+    constexpr int ITEMS = EVEN ? M / 2 : (M + 1) / 2;
+    constexpr int ITER = (ITEMS + 63) / 64;
+    float2 va[ITER][R], vb[ITER][R];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = t + it * 64;
+        if (ITER * 64 == ITEMS || i < ITEMS) {
+            const int jp = i ? M - i : (EVEN ? M / 2 : 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                va[it][r] = buf[pad<P::SWZ>(i + r * M)];
+                vb[it][r] = buf[pad<P::SWZ>(jp + r * M)];
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = t + it * 64;
+        if (ITER * 64 == ITEMS || i < ITEMS) {
+            const int jp = i ? M - i : (EVEN ? M / 2 : 0);
+            {
+                float2 w[R];
+                w[1] = twg[i];
+#pragma unroll
+                for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) va[it][r] = cmulf(va[it][r], w[r]);
+                w[1] = twg[jp];
+#pragma unroll
+                for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) vb[it][r] = cmulf(vb[it][r], w[r]);
+            }
+            Dft<R>::run(va[it]);
+            Dft<R>::run(vb[it]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // Z[k] = va[r]; Z[N-k] is output R-1-r of butterfly M-i, or output (R-r)%R of butterfly 0 itself
+                const int k = i + r * M;
+                const float2 zk = va[it][r];
+                const float2 zc = (i == 0) ? va[it][(R - r) % R] : vb[it][R - 1 - r];
+                const bool low = 2 * k <= N;
+                if (i != 0 || low) emit(low ? k : N - k, low ? zk : zc, low ? zc : zk);
+            }
+            if (EVEN && i == 0) {
+                // butterfly M/2: Z[M/2 + r M] pairs with Z[M/2 + (R-1-r) M]
+#pragma unroll
+                for (int r = 0; 2 * r < R; ++r) emit(M / 2 + r * M, vb[it][r], vb[it][R - 1 - r]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- kernels
 struct RowsArgs {
     const uint8_t* gray;
@@ -289,17 +413,24 @@ struct RowsArgs {
 // Persistent waves: each wave walks over (frame, row pair) units with a stride of the grid size and
 // issues the global loads of its NEXT unit before transforming the current one, so the HBM/L2
 // latency of the gray rows hides behind the butterflies.
-template <class P>
+//   DIRECT (one transform per wave, aligned rows, N/R0 in {64,128,256}): the first pass takes its inputs
+//   from the prefetch registers, the last pass splits and stores from registers (see above);
+//   otherwise the signal is staged in LDS first; sub-wave transforms also split through LDS.
+template <class P, bool DIRECT>
 __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[P::TPW * P::S];
     constexpr int N = P::N, LPT = P::LPT;
-    constexpr bool PREFETCH = (P::TPW == 1) && (N % 4 == 0);
-    constexpr int NL = PREFETCH ? (N / 4 + 63) / 64 : 1;  // dwords per lane and row
+    constexpr bool PAIRS = (LPT == 64);  // fused last pass
+    constexpr bool PREFETCH = !DIRECT && (P::TPW == 1) && (N % 4 == 0);
+    constexpr int NL = DIRECT ? P::R0 : (PREFETCH ? (N / 4 + 63) / 64 : 1);  // loads per lane and row
+    constexpr int NP = (P::R3 > 1) ? 4 : (P::R2 > 1) ? 3 : (P::R1 > 1) ? 2 : 1;
+    static_assert(!PAIRS || NP >= 2, "a fused first or last pass needs at least two passes");
     const int lane = threadIdx.x;
-    const int sub = lane / LPT, t = lane % LPT;
+    // one transform per wave: the row pair, its bounds tests and its addresses are wave-uniform
+    const int sub = (P::TPW == 1) ? 0 : lane / LPT, t = (P::TPW == 1) ? lane : lane % LPT;
     float2* buf = lds + sub * P::S;
     const int cbw = a.cbw;
-    const bool aligned = (a.fox & 3) == 0;
+    const bool aligned = DIRECT || (a.fox & 3) == 0;
 
     uint32_t ra_reg[NL], rb_reg[NL];
     auto row_ptr = [&](int unit, int& frame, int& ra) -> const uint8_t* {
@@ -313,23 +444,43 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         int frame, ra;
         const uint8_t* pa = row_ptr(unit, frame, ra);
         const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
+        if constexpr (DIRECT) {
+            constexpr int B = Direct<P>::B;
+            if (ina && inb) {  // wave-uniform; every unit but the last row pair of an odd-height frame
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int x4 = lane + 64 * i;
-            const bool inx = (NL * 64 == N / 4) || x4 < N / 4;
-            ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
-            rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0x80808080u;
+                for (int i = 0; i < NL; ++i) {
+                    ra_reg[i] = load_bytes<B>(pa, lane + 64 * i);
+                    rb_reg[i] = load_bytes<B>(pa + a.gpitch, lane + 64 * i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    ra_reg[i] = ina ? load_bytes<B>(pa, lane + 64 * i) : 0x80808080u;
+                    rb_reg[i] = 0x80808080u;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int x4 = lane + 64 * i;
+                const bool inx = (NL * 64 == N / 4) || x4 < N / 4;
+                ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
+                rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0x80808080u;
+            }
         }
     };
 
     int unit = blockIdx.x;
-    if (PREFETCH && aligned && unit < a.total_units) fetch(unit);
+    if ((DIRECT || (PREFETCH && aligned)) && unit < a.total_units) fetch(unit);
     for (; unit < a.total_units; unit += gridDim.x) {
         int frame, ra;
         const uint8_t* pa = row_ptr(unit, frame, ra);
         const uint8_t* pb = pa + a.gpitch;
         const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
-        if (PREFETCH && aligned) {
+        if constexpr (DIRECT) {
+            pass0_direct<P>(buf, ra_reg, rb_reg, t);
+            if (unit + (int)gridDim.x < a.total_units) fetch(unit + gridDim.x);
+        } else if (PREFETCH && aligned) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const int x4 = lane + 64 * i;
@@ -366,18 +517,38 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                 buf[pad<P::SWZ>(x)] =
                     make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
         }
-        transform<P>(buf, a.tw, t);
-        if (ina) {
-            // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
-            float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw;
-            for (int k = t; k <= N / 2; k += LPT) {
-                const float2 zk = buf[pad<P::SWZ>(k)];
-                const float2 zc = buf[pad<P::SWZ>(k ? N - k : 0)];
-                const int kb = k >> a.cbw_log2, kc = k & (cbw - 1);
-                float2* o = base + (((int64_t)kb * a.fh + ra) << a.cbw_log2) + kc;
+        // One half-spectrum bin of both rows; column-blocked layout [kb][row][cbw].  The row part of the
+        // address is wave-uniform (folded into the base pointer); the bin part depends on the lane only,
+        // so it stays a 32-bit offset that does not change from unit to unit.
+        float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw + ((int64_t)ra << a.cbw_log2);
+        auto emit = [&](int k, float2 zk, float2 zc) {
+            if (ina) {
+                const uint32_t off = ((((uint32_t)k >> a.cbw_log2) * (uint32_t)a.fh) << a.cbw_log2) + ((uint32_t)k & (uint32_t)(cbw - 1));
+                float2* o = base + off;
                 o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
                 if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
             }
+        };
+        if constexpr (PAIRS) {
+            StoreSink<P::SWZ> st{buf};
+            if constexpr (!DIRECT) {
+                wave_sync();  // the signal was stored by other lanes
+                pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
+            }
+            if constexpr (NP == 2) {
+                last_pass_pairs<P, P::R1>(buf, a.tw, t, emit);
+            } else if constexpr (NP == 3) {
+                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, a.tw, t, st);
+                last_pass_pairs<P, P::R2>(buf, a.tw, t, emit);
+            } else {
+                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, a.tw, t, st);
+                pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, a.tw, t, st);
+                last_pass_pairs<P, P::R3>(buf, a.tw, t, emit);
+            }
+        } else {
+            transform<P>(buf, a.tw, t);
+            // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
+            for (int k = t; k <= N / 2; k += LPT) emit(k, buf[pad<P::SWZ>(k)], buf[pad<P::SWZ>(k ? N - k : 0)]);
         }
         wave_sync();  // the next unit's signal overwrites what other lanes have just read
     }
@@ -487,7 +658,14 @@ void launch_rows_t(hipStream_t s, RowsArgs a, int n_frames) {
     int per_cu = (160 * 1024) / (lds_bytes + 256);
     per_cu = per_cu > 16 ? 16 : (per_cu < 1 ? 1 : per_cu);
     const int grid = a.total_units < 256 * per_cu ? a.total_units : 256 * per_cu;
-    hipLaunchKernelGGL(rows_kernel<P>, dim3(grid), dim3(64), 0, s, a);
+    if constexpr (Direct<P>::ok) {
+        // narrow loads need B-byte aligned rows: gray rows start 4-byte aligned, the crop origin decides
+        if ((a.fox & 3) == 0 && (a.gpitch & 3) == 0) {
+            hipLaunchKernelGGL((rows_kernel<P, true>), dim3(grid), dim3(64), 0, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((rows_kernel<P, false>), dim3(grid), dim3(64), 0, s, a);
 }
 
 template <class P>

@@ -471,7 +471,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 }
 
 template <bool DO_LBP, bool CODES>
-__global__ __launch_bounds__(256) void stencil_kernel(StencilArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stencil_kernel(StencilArgs a) {
     __shared__ uint32_t tile[LROWS * LDW];
     __shared__ unsigned long long lut[LUT_INVALID + 2];
     __shared__ uint32_t red[4][16];
