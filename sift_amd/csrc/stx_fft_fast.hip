@@ -81,9 +81,15 @@ __device__ __forceinline__ float2 cmulf_const(float2 a, float kre, float kim) {
 template <int R>
 __device__ __forceinline__ float2 mul_tw(float2 v, int m, const Tw<R>& tw) {
     if (m == 0) return v;
-    if (4 * m == R) return make_float2(v.y, -v.x);
+    if (4 * m == R || 4 * m == 3 * R) {
+        // times -i or +i: swap the halves, flip one sign, in a single packed add with zero
+        const v2f a = __builtin_bit_cast(v2f, v);
+        v2f r;
+        if (4 * m == R) asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+        else asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a));
+        return __builtin_bit_cast(float2, r);
+    }
     if (2 * m == R) return make_float2(-v.x, -v.y);
-    if (4 * m == 3 * R) return make_float2(-v.y, v.x);
     return cmulf_const(v, tw.re[m], tw.im[m]);
 }
 
@@ -126,39 +132,65 @@ template <>
 struct Dft<1> {
     static __device__ __forceinline__ void run(float2 (&)[1]) {}
 };
+// Radix kernels on packed pairs.  A multiplication by -i or +i is a swap of the halves with one sign
+// flip; the packed-f32 operand selectors do that inside the add that consumes it, so no rotation ever
+// costs an instruction of its own.
+__device__ __forceinline__ v2f V(float2 a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ float2 F(v2f a) { return __builtin_bit_cast(float2, a); }
+// a + (-i) d = (a.x + d.y, a.y - d.x)
+__device__ __forceinline__ v2f add_mi(v2f a, v2f d) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+// a + (+i) d = (a.x - d.y, a.y + d.x)
+__device__ __forceinline__ v2f add_pi(v2f a, v2f d) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+// a + c (-i) d  and  a - c (-i) d, c a compile-time real constant held in a scalar pair
+__device__ __forceinline__ v2f fma_mi(v2f a, float c, v2f d) {
+    const v2f k = {c, -c};
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(d), "s"(k), "v"(a));
+    return r;
+}
+__device__ __forceinline__ v2f fma_pi(v2f a, float c, v2f d) {
+    const v2f k = {-c, c};
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(d), "s"(k), "v"(a));
+    return r;
+}
+
 template <>
 struct Dft<2> {
     static __device__ __forceinline__ void run(float2 (&v)[2]) {
-        const float2 a = v[0], b = v[1];
-        v[0] = make_float2(a.x + b.x, a.y + b.y);
-        v[1] = make_float2(a.x - b.x, a.y - b.y);
+        const v2f a = V(v[0]), b = V(v[1]);
+        v[0] = F(a + b);
+        v[1] = F(a - b);
     }
 };
 template <>
 struct Dft<3> {
     static __device__ __forceinline__ void run(float2 (&v)[3]) {
         const float c = 0.86602540378443864676f;
-        const float2 s = make_float2(v[1].x + v[2].x, v[1].y + v[2].y);
-        const float2 d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
-        const float2 h = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
-        const float2 r = make_float2(c * d.y, -c * d.x);
-        v[0] = make_float2(v[0].x + s.x, v[0].y + s.y);
-        v[1] = make_float2(h.x + r.x, h.y + r.y);
-        v[2] = make_float2(h.x - r.x, h.y - r.y);
+        const v2f v0 = V(v[0]), s = V(v[1]) + V(v[2]), d = V(v[1]) - V(v[2]);
+        const v2f h = v0 - 0.5f * s;
+        v[0] = F(v0 + s);
+        v[1] = F(fma_mi(h, c, d));  // h + c (-i) d
+        v[2] = F(fma_pi(h, c, d));  // h - c (-i) d
     }
 };
 template <>
 struct Dft<4> {
     static __device__ __forceinline__ void run(float2 (&v)[4]) {
-        const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
-        const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
-        const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
-        const float2 d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
-        const float2 a3 = make_float2(d.y, -d.x);
-        v[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-        v[1] = make_float2(a1.x + a3.x, a1.y + a3.y);
-        v[2] = make_float2(a0.x - a2.x, a0.y - a2.y);
-        v[3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+        const v2f a0 = V(v[0]) + V(v[2]), a1 = V(v[0]) - V(v[2]);
+        const v2f a2 = V(v[1]) + V(v[3]), d = V(v[1]) - V(v[3]);
+        v[0] = F(a0 + a2);
+        v[1] = F(add_mi(a1, d));
+        v[2] = F(a0 - a2);
+        v[3] = F(add_pi(a1, d));
     }
 };
 template <>
@@ -166,18 +198,18 @@ struct Dft<5> {
     static __device__ __forceinline__ void run(float2 (&v)[5]) {
         const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
         const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-        const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y);
-        const float2 b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
-        const float2 p1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-        const float2 p2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-        const float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-        const float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
-        const float2 q1 = make_float2(u1.y, -u1.x), q2 = make_float2(u2.y, -u2.x);
-        v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
-        v[1] = make_float2(p1.x + q1.x, p1.y + q1.y);
-        v[2] = make_float2(p2.x + q2.x, p2.y + q2.y);
-        v[3] = make_float2(p2.x - q2.x, p2.y - q2.y);
-        v[4] = make_float2(p1.x - q1.x, p1.y - q1.y);
+        const v2f v0 = V(v[0]);
+        const v2f a1 = V(v[1]) + V(v[4]), a2 = V(v[2]) + V(v[3]);
+        const v2f b1 = V(v[1]) - V(v[4]), b2 = V(v[2]) - V(v[3]);
+        const v2f p1 = v0 + c1 * a1 + c2 * a2;
+        const v2f p2 = v0 + c2 * a1 + c1 * a2;
+        const v2f u1 = s1 * b1 + s2 * b2;
+        const v2f u2 = s2 * b1 - s1 * b2;
+        v[0] = F(v0 + a1 + a2);
+        v[1] = F(add_mi(p1, u1));
+        v[2] = F(add_mi(p2, u2));
+        v[3] = F(add_pi(p2, u2));
+        v[4] = F(add_pi(p1, u1));
     }
 };
 
