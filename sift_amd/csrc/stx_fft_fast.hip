@@ -255,8 +255,22 @@ struct StoreSink {
     __device__ __forceinline__ void operator()(int idx, float2 v) const { buf[pad<SWZ>(idx)] = v; }
 };
 
-template <int N, int R, int NS, int LPT, bool SWZ, class Sink>
-__device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t, Sink& sink) {
+// Where a pass takes its one table twiddle per butterfly from: the table in global memory, or registers
+// that a persistent kernel filled once (the index depends on the lane only, not on the transform; and a
+// global load inside the loop would make the wave wait for its own earlier stores to drain, because
+// loads and stores retire through one in-order counter).
+struct TwGlobal {
+    const float2* p;
+    __device__ __forceinline__ float2 get(int, int idx) const { return p[idx]; }
+};
+template <int NSLOT>
+struct TwRegs {
+    float2 v[NSLOT];
+    __device__ __forceinline__ float2 get(int slot, int) const { return v[slot]; }
+};
+
+template <int N, int R, int NS, int LPT, bool SWZ, class Sink, class TwS>
+__device__ __forceinline__ void pass(float2* __restrict__ buf, const TwS& twg, int t, Sink& sink) {
     if constexpr (R > 1) {
         constexpr int M = N / R;
         constexpr int ITER = (M + LPT - 1) / LPT;
@@ -278,7 +292,7 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
                 if constexpr (NS > 1) {
                     // w^(r k), w = exp(-2 pi i / (NS R)): one table read, the other powers by products
                     float2 w[R];
-                    w[1] = twg[k * (N / (NS * R))];
+                    w[1] = twg.get(it, k * (N / (NS * R)));
 #pragma unroll
                     for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
 #pragma unroll
@@ -292,6 +306,24 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
         }
         wave_sync();  // the next phase reads what other lanes wrote
     }
+}
+
+template <int N, int R, int NS, int LPT, bool SWZ, class Sink>
+__device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __restrict__ twg, int t, Sink& sink) {
+    const TwGlobal g{twg};
+    pass<N, R, NS, LPT, SWZ>(buf, g, t, sink);
+}
+// the table twiddles of a pass, loaded once
+template <int N, int R, int NS>
+__device__ __forceinline__ TwRegs<(N / R + 63) / 64> load_pass_twiddles(const float2* __restrict__ twg, int t) {
+    constexpr int M = N / R, ITER = (M + 63) / 64;
+    TwRegs<ITER> r;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int j = t + it * 64;
+        r.v[it] = twg[(j < M ? j % NS : 0) * (N / (NS * R))];
+    }
+    return r;
 }
 
 // last: receives the outputs of the final pass (index, value) instead of the LDS buffer
@@ -371,9 +403,30 @@ __device__ __forceinline__ void pass0_direct(float2* __restrict__ buf, const uin
 // go from registers to global memory, and the pass neither writes LDS nor is re-read by a split loop.
 // Work item i = 1..(M-1)/2 runs butterflies i and M-i.  Butterflies 0 and (M even) M/2 hold their own
 // partners; item 0 runs those two.  emit(k, Z[k], Z[N-k]) is called once for every k in 0..N/2.
-template <class P, int R, class Emit>
-__device__ __forceinline__ void last_pass_pairs(const float2* __restrict__ buf, const float2* __restrict__ twg, int t,
-                                                Emit& emit) {
+template <class P, int R>
+struct PairItems {
+    static constexpr int M = P::N / R;
+    static constexpr bool EVEN = (M % 2) == 0;
+    static constexpr int ITEMS = EVEN ? M / 2 : (M + 1) / 2;
+    static constexpr int ITER = (ITEMS + 63) / 64;
+};
+template <class P, int R>
+__device__ __forceinline__ TwRegs<2 * PairItems<P, R>::ITER> load_pair_twiddles(const float2* __restrict__ twg, int t) {
+    using PI = PairItems<P, R>;
+    TwRegs<2 * PI::ITER> r;
+#pragma unroll
+    for (int it = 0; it < PI::ITER; ++it) {
+        int i = t + it * 64;
+        if (i >= PI::ITEMS) i = 0;
+        const int jp = i ? PI::M - i : (PI::EVEN ? PI::M / 2 : 0);
+        r.v[2 * it] = twg[i];
+        r.v[2 * it + 1] = twg[jp];
+    }
+    return r;
+}
+
+template <class P, int R, class Emit, class TwS>
+__device__ __forceinline__ void last_pass_pairs(const float2* __restrict__ buf, const TwS& twg, int t, Emit& emit) {
     constexpr int N = P::N, M = N / R;
     constexpr bool EVEN = (M % 2) == 0;
     constexpr int ITEMS = EVEN ? M / 2 : (M + 1) / 2;
@@ -398,12 +451,12 @@ __device__ __forceinline__ void last_pass_pairs(const float2* __restrict__ buf, 
             const int jp = i ? M - i : (EVEN ? M / 2 : 0);
             {
                 float2 w[R];
-                w[1] = twg[i];
+                w[1] = twg.get(2 * it, i);
 #pragma unroll
                 for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
 #pragma unroll
                 for (int r = 1; r < R; ++r) va[it][r] = cmulf(va[it][r], w[r]);
-                w[1] = twg[jp];
+                w[1] = twg.get(2 * it + 1, jp);
 #pragma unroll
                 for (int r = 2; r < R; ++r) w[r] = cmulf(w[r / 2], w[r - r / 2]);
 #pragma unroll
@@ -502,6 +555,12 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         }
     };
 
+    // table twiddles of the passes after the first, once per wave
+    constexpr int RL = (NP == 2) ? P::R1 : (NP == 3) ? P::R2 : P::R3;  // radix of the last pass
+    [[maybe_unused]] const auto tw_last = load_pair_twiddles<P, PAIRS ? RL : P::N>(a.tw, t);
+    [[maybe_unused]] const auto tw_p1 = load_pass_twiddles<P::N, (PAIRS && NP >= 3) ? P::R1 : P::N, P::R0>(a.tw, t);
+    [[maybe_unused]] const auto tw_p2 = load_pass_twiddles<P::N, (PAIRS && NP == 4) ? P::R2 : P::N, P::R0 * P::R1>(a.tw, t);
+
     int unit = blockIdx.x;
     if ((DIRECT || (PREFETCH && aligned)) && unit < a.total_units) fetch(unit);
     for (; unit < a.total_units; unit += gridDim.x) {
@@ -568,14 +627,14 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                 pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
             }
             if constexpr (NP == 2) {
-                last_pass_pairs<P, P::R1>(buf, a.tw, t, emit);
+                last_pass_pairs<P, P::R1>(buf, tw_last, t, emit);
             } else if constexpr (NP == 3) {
-                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, a.tw, t, st);
-                last_pass_pairs<P, P::R2>(buf, a.tw, t, emit);
+                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
+                last_pass_pairs<P, P::R2>(buf, tw_last, t, emit);
             } else {
-                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, a.tw, t, st);
-                pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, a.tw, t, st);
-                last_pass_pairs<P, P::R3>(buf, a.tw, t, emit);
+                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
+                pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, tw_p2, t, st);
+                last_pass_pairs<P, P::R3>(buf, tw_last, t, emit);
             }
         } else {
             transform<P>(buf, a.tw, t);
