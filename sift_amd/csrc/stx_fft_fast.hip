@@ -561,8 +561,21 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     [[maybe_unused]] const auto tw_p1 = load_pass_twiddles<P::N, (PAIRS && NP >= 3) ? P::R1 : P::N, P::R0>(a.tw, t);
     [[maybe_unused]] const auto tw_p2 = load_pass_twiddles<P::N, (PAIRS && NP == 4) ? P::R2 : P::N, P::R0 * P::R1>(a.tw, t);
 
+    // Loads and stores retire through one in-order counter, so waiting for the prefetched rows at the
+    // top of a unit would also wait for the previous unit's freshly issued stores.  The prefetch registers
+    // are therefore touched BEFORE a unit's stores go out (and once before the loop): by then the loads
+    // have had the middle passes to arrive, and the only older memory operations are stores of the unit
+    // before, long since retired.
+    auto settle_prefetch = [&]() {
+        if constexpr (DIRECT || PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(ra_reg[i]), "+v"(rb_reg[i]));
+        }
+    };
+
     int unit = blockIdx.x;
     if ((DIRECT || (PREFETCH && aligned)) && unit < a.total_units) fetch(unit);
+    settle_prefetch();
     for (; unit < a.total_units; unit += gridDim.x) {
         int frame, ra;
         const uint8_t* pa = row_ptr(unit, frame, ra);
@@ -627,17 +640,21 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                 pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
             }
             if constexpr (NP == 2) {
+                settle_prefetch();
                 last_pass_pairs<P, P::R1>(buf, tw_last, t, emit);
             } else if constexpr (NP == 3) {
                 pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
+                settle_prefetch();
                 last_pass_pairs<P, P::R2>(buf, tw_last, t, emit);
             } else {
                 pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
                 pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, tw_p2, t, st);
+                settle_prefetch();
                 last_pass_pairs<P, P::R3>(buf, tw_last, t, emit);
             }
         } else {
             transform<P>(buf, a.tw, t);
+            settle_prefetch();
             // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
             for (int k = t; k <= N / 2; k += LPT) emit(k, buf[pad<P::SWZ>(k)], buf[pad<P::SWZ>(k ? N - k : 0)]);
         }
@@ -665,13 +682,26 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     // the block [N][cbw] is contiguous in global memory
     const float2* src = a.spec + ((int64_t)frame * a.nkb + kb) * (int64_t)N * cbw;
     if (cbw >= 2) {
+        // N*cbw/2 16-byte loads over 64*cbw/TPW threads: N*TPW/128 per thread whatever cbw is.  All of a
+        // thread's loads are issued before the first LDS write, so the block arrives at memory latency once,
+        // not once per load.
         const float4* src4 = reinterpret_cast<const float4*>(src);
         const int half = cbw >> 1;
-        for (int e = tid; e < N * half; e += nthreads) {
-            const float4 q = src4[e];
-            const int y = e >> (a.cbw_log2 - 1), c = 2 * (e & (half - 1));
-            dynlds[c * S + pad<P::SWZ>(y)] = make_float2(q.x, q.y);
-            dynlds[(c + 1) * S + pad<P::SWZ>(y)] = make_float2(q.z, q.w);
+        constexpr int LOADS = (N * P::TPW + 127) / 128;
+        float4 q[LOADS];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int e = tid + i * nthreads;
+            q[i] = (e < N * half) ? src4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int e = tid + i * nthreads;
+            if (e < N * half) {
+                const int y = e >> (a.cbw_log2 - 1), c = 2 * (e & (half - 1));
+                dynlds[c * S + pad<P::SWZ>(y)] = make_float2(q[i].x, q[i].y);
+                dynlds[(c + 1) * S + pad<P::SWZ>(y)] = make_float2(q[i].z, q[i].w);
+            }
         }
     } else {
         for (int y = tid; y < N; y += nthreads) dynlds[pad<P::SWZ>(y)] = src[y];
