@@ -17,8 +17,11 @@
 // are bilinear.  Their sign against the centre is first decided in 16.16 fixed point (two
 // v_dot2_u32_u16 per sample); the rounded weights put that value within about 140/65536 of the exact
 // one (the bound is computed from the actual rounding errors at launch), so anything further
-// than that from the centre has the sign scikit-image's fp64 arithmetic produces.  Pixels with a closer sample are queued and re-evaluated per lane in the
-// order-exact fp64 sequence.  This file must be compiled with -ffp-contract=off.
+// than that from the centre has the sign scikit-image's fp64 arithmetic produces.  Pixels with a
+// closer sample (exact ties, mostly: about 3 % of the pixels of a low-contrast image) go through a
+// wave-wide queue in LDS and are re-evaluated in the order-exact fp64 sequence by whichever lane is
+// free, so the slow path costs ceil(queued / 64) rounds per block of rows instead of the worst lane's
+// count.  This file must be compiled with -ffp-contract=off.
 #include "stx_internal.h"
 
 namespace stx {
@@ -36,6 +39,7 @@ constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+TILE_H+1
 constexpr int LPITCH = TILE_W + 8; // bytes: columns x0-4 .. x0+131
 constexpr int LDW = LPITCH / 4;
 constexpr int LUT_INVALID = 256;       // histogram table slot that adds nothing
+constexpr int QUEUE_ITEMS = BLOCK_ROWS * TILE_W;  // pixels of one wave's block of rows
 
 // ---- packed 16-bit helpers (operands travel as plain 32-bit words) ----
 __device__ __forceinline__ us2 asU(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -99,6 +103,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64s(unsigned long long v
 
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Lanes of one wave exchange data through LDS without a barrier instruction (a wave's LDS operations
+// execute in issue order); this wavefront-scope fence only keeps the COMPILER from moving a lane's load
+// above its own earlier store.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One bilinear sample exactly as skimage's bilinear_interpolation: top/bottom rows first,
 // then the vertical blend; returns the LBP bit (sample - centre >= 0).
 __device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, double bl, double br, double dr, double dc,
@@ -139,6 +152,7 @@ struct RowD {
 
 template <bool BORDER, bool DO_LBP, bool CODES>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const unsigned long long* lut,
+                                      uint16_t* wq /*[QUEUE_ITEMS] per wave*/, uint32_t* wsg /*[128] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
     const int x = x0 + 2 * lane;  // this lane's pixels: x (low half) and x+1 (high half)
@@ -363,18 +377,18 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 mg[1] = mg[2];
             }
             if (DO_LBP) {
-                // ---- LBP second stage: queued pixels, one per lane and iteration, all four diagonal samples
-                // in the fp64 arithmetic of skimage's bilinear_interpolation (operands re-read from the tile)
-                auto lbp_px = [&](int yy, int xx) -> double {
-                    if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
-                    return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
-                };
-                while (__any(pend != 0)) {
-                    if (pend != 0) {
-                        const int slot = 2 * BLOCK_ROWS - __ffs(pend);  // 0 = row 0 low pixel, 1 = row 0 high pixel, ...
-                        pend &= pend - 1;
-                        const int i = slot >> 1, e = slot & 1;
-                        const int y = yb + i, xx = x + e;
+                // ---- LBP second stage.  Every lane appends its queued pixels to the wave's queue (positions from
+                // a prefix sum of the counts) and parks its diagonal nibbles in LDS; then lane l takes queue entry
+                // l, l+64, ...: all four diagonal samples of that pixel in the fp64 arithmetic of skimage's
+                // bilinear_interpolation (operands re-read from the tile), patched into the owner's nibble.
+                const uint32_t cnt = __popc(pend);
+                if (__any(cnt != 0)) {
+                    auto lbp_px = [&](int yy, int xx) -> double {
+                        if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
+                        return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+                    };
+                    // the four diagonal sign bits (samples 1,3,5,7 from bit 3 down; 1 = below the centre) of one pixel
+                    auto exact_nibble = [&](int y, int xx) -> uint32_t {
                         double n[3][3];
 #pragma unroll
                         for (int r = 0; r < 3; ++r)
@@ -389,10 +403,64 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
                         const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
                         const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
-                        const uint32_t nib = (((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu) << (4 * (BLOCK_ROWS - 1 - i));
-                        const uint32_t keep = ~(0xFu << (4 * (BLOCK_ROWS - 1 - i)));
-                        if (e) sgd_hi = (sgd_hi & keep) | nib;
-                        else sgd_lo = (sgd_lo & keep) | nib;
+                        return ((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu;
+                    };
+                    uint32_t inc = cnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t up = __shfl_up(inc, o, 64);
+                        inc += (lane >= o) ? up : 0u;
+                    }
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    // flat regions queue (nearly) every pixel: the lanes are evenly loaded as they are, and each
+                    // keeps its own pixels (no queue, no LDS atomics on a shared word)
+                    const bool dense = total > QUEUE_ITEMS / 4;
+                    if (!dense) {
+                        uint32_t qpos = inc - cnt;
+                        wsg[2 * lane] = sgd_lo;
+                        wsg[2 * lane + 1] = sgd_hi;
+                        while (pend != 0) {
+                            const uint32_t slot = 2 * BLOCK_ROWS - __ffs(pend);  // 0 = row 0 low pixel, 1 = row 0 high pixel, ...
+                            pend &= pend - 1;
+                            wq[qpos++] = (uint16_t)(((uint32_t)lane << 4) | slot);
+                        }
+                        wave_sync();
+                    }
+                    for (uint32_t qb = 0;; qb += 64) {
+                        bool active;
+                        uint32_t item = 0;
+                        if (dense) {
+                            active = pend != 0;
+                            if (!__any(active)) break;
+                            if (active) {
+                                item = ((uint32_t)lane << 4) | (uint32_t)(2 * BLOCK_ROWS - __ffs(pend));
+                                pend &= pend - 1;
+                            }
+                        } else {
+                            if (qb >= total) break;
+                            active = qb + lane < total;
+                            if (active) item = wq[qb + lane];
+                        }
+                        if (active) {
+                            const int owner = item >> 4, i = (item & 15) >> 1, e = item & 1;
+                            const int sh = 4 * (BLOCK_ROWS - 1 - i);
+                            const uint32_t nib = exact_nibble(yb + i, x0 + 2 * owner + e) << sh;
+                            if (dense) {
+                                if (e) sgd_hi = (sgd_hi & ~(0xFu << sh)) | nib;
+                                else sgd_lo = (sgd_lo & ~(0xFu << sh)) | nib;
+                            } else {
+                                // distinct entries never share a nibble, so the two read-modify-writes need no
+                                // ordering against other lanes; LDS atomics keep each of them whole
+                                atomicAnd(&wsg[2 * owner + e], ~(0xFu << sh));
+                                atomicOr(&wsg[2 * owner + e], nib);
+                            }
+                        }
+                    }
+                    if (!dense) {
+                        wave_sync();
+                        sgd_lo = wsg[2 * lane];
+                        sgd_hi = wsg[2 * lane + 1];
+                        wave_sync();  // the next block's queue must not overtake these reads
                     }
                 }
                 // ---- codes and histogram of this block: the eight sign bits index a table of 1 << 6*code
@@ -474,6 +542,8 @@ template <bool DO_LBP, bool CODES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stencil_kernel(StencilArgs a) {
     __shared__ uint32_t tile[LROWS * LDW];
     __shared__ unsigned long long lut[LUT_INVALID + 2];
+    __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
+    __shared__ uint32_t wsg[4][128];
     __shared__ uint32_t red[4][16];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * TILE_W;
@@ -512,9 +582,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wsg[wv], frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wsg[wv], frame, x0, y0, lane, wv, red[wv]);
     } else if ((ys >> 6) < a.bm_words) {
         // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
         const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
