@@ -48,7 +48,7 @@ GROUPS = {"texture": ("gray", "stencil", "lbp_generic"), "hysteresis": ("hystere
 
 def measured_traffic(h: int, w: int):
     """Per-frame HBM bytes per kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r1_b_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_c_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -207,7 +207,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8/int32 stencils, f64 LBP interpolation, f32 FFT",
+            "dtype": "u8 -> packed u16 stencils, 16.16 fixed-point LBP pre-decision with f64 tie-breaks, f32 FFT, f64 sums",
             "data": "synthetic",
             "config": {"workload": f"{h}p {args.kind} clips, {nf} frames x {w}x{h} BGR u8 per step per GPU, "
                                    "full-frame texture analysis (BASELINE configs[2])",
@@ -221,8 +221,10 @@ def main() -> None:
                 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_frame": ab[dom], "frames_per_launch": frames_per_launch,
                 "avg_launch_ms": avg_ms,
-                "note": "the stencil kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~ 99% of SIMD cycles, profiles/), "
-                        "so the HBM fraction is capped by instruction issue, not by memory",
+                "note": "kernel durations in the timed region include the stretch from running beside the other "
+                        "stream's kernels; frac_serialized prices the same group alone on the device. The "
+                        "stencil kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~ 88% of SIMD cycles, profiles/), so "
+                        "the path's HBM fraction is capped by instruction issue, not by memory",
                 "path": {"algorithmic_bytes_per_frame": ab["path"], "achieved": path_gbs,
                          "frac": path_gbs / HBM_PEAK_GBS},
             },
