@@ -33,14 +33,23 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
 // that pass".  From pass 1 on a tile is revisited only if it or one of its eight neighbours
 // changed in the previous pass.  nlines = image width, nwords = words per line, ntiles =
 // 64-line tiles across the image.
-__global__ __launch_bounds__(64) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
-                                                       const unsigned long long* __restrict__ cand, int nlines,
-                                                       int nwords, int ntiles, unsigned int* changed, int pass,
-                                                       uint32_t* __restrict__ tile_count, uint8_t* tflag,
-                                                       int64_t tflag_half) {
+// Four independent tiles per workgroup (one per wave): most passes after the first only look at their
+// flags and leave, and then the cost of a pass is the number of workgroups to dispatch.
+constexpr int HYST_WAVES = 4;
+__global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
+                                                                    const unsigned long long* __restrict__ cand,
+                                                                    int nlines, int nwords, int ntiles, int total_tiles,
+                                                                    unsigned int* changed, int pass,
+                                                                    uint32_t* __restrict__ tile_count, uint8_t* tflag,
+                                                                    int64_t tflag_half) {
     if (pass > 0 && changed[pass - 1] == 0) return;
-    const int frame = blockIdx.z, tl = blockIdx.y, wx = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tile_id = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6);
+    if (tile_id >= total_tiles) return;
+    const int tpf = ntiles * nwords;
+    const int frame = tile_id / tpf;
+    const int rem = tile_id - frame * tpf;
+    const int tl = rem / nwords, wx = rem - tl * nwords;
+    const int lane = threadIdx.x & 63;
     const int64_t tbase = (int64_t)frame * ntiles * nwords;
     uint8_t* fl_cur = tflag + (int64_t)(pass & 1) * tflag_half + tbase;
     if (pass > 0) {
@@ -179,10 +188,10 @@ __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long l
 
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
-    dim3 grid(g.bm_words, g.bm_tiles, n_frames);
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
-    hipLaunchKernelGGL(hyst_pass_kernel, grid, dim3(64), 0, s, strong, cand, g.W, g.bm_words, g.bm_tiles, changed, pass,
-                       tile_count, tflag, half);
+    const int total = (int)half;
+    hipLaunchKernelGGL(hyst_pass_kernel, dim3((total + HYST_WAVES - 1) / HYST_WAVES), dim3(64 * HYST_WAVES), 0, s, strong,
+                       cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
