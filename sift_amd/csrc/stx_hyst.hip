@@ -72,9 +72,17 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
     const bool lin = ln < nlines;
     const bool hasl = wx > 0, hasr = wx + 1 < nwords;  // previous / next word along the lines
     unsigned long long S = 0, C = 0, Lw = 0, Rw = 0;
+    if (lin) C = cb[ln];
+    if (!__any(C != 0)) {
+        // no candidate in the tile (strong pixels are candidates too): nothing here can ever change
+        if (lane == 0) {
+            fl_cur[tl * nwords + wx] = 0;
+            tile_count[tbase + tl * nwords + wx] = 0;
+        }
+        return;
+    }
     if (lin) {
         S = sb[ln];
-        C = cb[ln];
         if (hasl) Lw = sb[ln - nlines];
         if (hasr) Rw = sb[ln + nlines];
     }
