@@ -19,7 +19,7 @@ def run(label, kind, **kw):
     tm = ctx.get_timing(reset=True)["kernels"]
     print(label, {k: round(v["ms"]/3, 3) for k, v in tm.items() if v["launches"]}, "edge", round(out[0].edge_density, 4), flush=True)
 run("natural full      ", 1)
-run("natural noLBP(R=2)", 1, lbp_radius=2.0)
+run("natural P8 R2      ", 1, lbp_radius=2.0); run("natural P16 R2     ", 1, lbp_points=16, lbp_radius=2.0); run("natural P24 R3     ", 1, lbp_points=24, lbp_radius=3.0); run("noise P24 R3       ", 0, lbp_points=24, lbp_radius=3.0)
 run("natural noNMS     ", 1, canny_low=30000, canny_high=30001)
 run("natural noLBP noNMS", 1, lbp_radius=2.0, canny_low=30000, canny_high=30001)
 run("noise full        ", 0)

@@ -47,7 +47,7 @@ struct Prepared {
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
-    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, acc, changed, staging;
+    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, acc, changed, staging;
     FrameAcc* acc_host = nullptr;  // pinned
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
@@ -386,9 +386,12 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         sp.end();
     }
     if (!lbp81) {
-        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 1, s);
-        launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, 0, acc, opts.codes);
+        if ((rc = ensure(c, sl.lpart, lbp_generic_part_bytes(g, F))) != STX_OK) return rc;
+        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 2, s);
+        const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, (uint32_t*)sl.lpart.p, acc,
+                                           opts.codes);
         sp.end();
+        if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
     }
     // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
     // changed nothing); finish_chunk() checks the last counter and only then adds more
@@ -526,7 +529,7 @@ int stx_destroy(stx_ctx* c) {
     (void)hipSetDevice(c->device);
     sync_all(c);
     for (Slot& sl : c->slot) {
-        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc, &sl.changed, &sl.staging};
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);

@@ -62,8 +62,11 @@ void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out);
 
-void launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
-                        int halo, FrameAcc* acc, uint8_t* codes_out);
+// Any (P <= 24, R): per-tile histograms into part (lbp_generic_part_bytes), then summed into acc[].lbp_hist.
+// Returns false when the radius needs a halo that does not fit an LDS tile.
+size_t lbp_generic_part_bytes(const Geom& g, int n_frames);
+bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
+                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out);
 
 // One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
 // changed nothing.  changed[] must be zeroed before pass 0.  tile_count: [frame][bm_tiles][bm_words].
