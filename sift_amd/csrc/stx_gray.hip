@@ -24,7 +24,8 @@ struct __attribute__((aligned(4))) Bgr4 {
 
 constexpr int GRAY_ROWS_PER_BLOCK = 4;
 
-// grid: x = 256-dword column blocks of a padded gray row, y = groups of 4 padded rows, z = frame.
+// grid: x = 256-thread blocks over (group of 4 padded rows, dword column) pairs, z = frame; the pairs are
+// numbered row group major, so narrow frames (crops) fill their workgroups too.
 // A thread converts the same four-pixel column of four consecutive rows: four independent 12-byte
 // loads in flight per lane, and a quarter of the workgroups to dispatch.
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ bgr, int64_t row_stride,
@@ -32,8 +33,10 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
                                                    int shift15, int aligned4, uint8_t* __restrict__ gray) {
     const int frame = blockIdx.z;
     const int dpr = gpitch >> 2;
-    const int dc = blockIdx.x * 256 + threadIdx.x;
-    if (dc >= dpr) return;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int rgroup = id / dpr;
+    const int dc = id - rgroup * dpr;
+    if (rgroup * GRAY_ROWS_PER_BLOCK >= grows) return;
     const int x = 4 * dc - GRAY_XOFF;
     const uint8_t* fsrc = bgr + (int64_t)frame * frame_stride;
     const bool fast = aligned4 && x >= 0 && x + 3 < W;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
         Bgr4 v[GRAY_ROWS_PER_BLOCK];
 #pragma unroll
         for (int j = 0; j < GRAY_ROWS_PER_BLOCK; ++j) {
-            int ry = blockIdx.y * GRAY_ROWS_PER_BLOCK + j;
+            int ry = rgroup * GRAY_ROWS_PER_BLOCK + j;
             ry = ry < grows ? ry : grows - 1;
             const int sy = reflect101(ry - GRAY_YOFF, H);
             v[j] = *reinterpret_cast<const Bgr4*>(fsrc + (int64_t)sy * row_stride + 3 * x);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
     } else {
 #pragma unroll
         for (int j = 0; j < GRAY_ROWS_PER_BLOCK; ++j) {
-            int ry = blockIdx.y * GRAY_ROWS_PER_BLOCK + j;
+            int ry = rgroup * GRAY_ROWS_PER_BLOCK + j;
             ry = ry < grows ? ry : grows - 1;
             const uint8_t* src = fsrc + (int64_t)reflect101(ry - GRAY_YOFF, H) * row_stride;
             uint32_t o = 0;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
     }
 #pragma unroll
     for (int j = 0; j < GRAY_ROWS_PER_BLOCK; ++j) {
-        const int ry = blockIdx.y * GRAY_ROWS_PER_BLOCK + j;
+        const int ry = rgroup * GRAY_ROWS_PER_BLOCK + j;
         if (ry < grows) reinterpret_cast<uint32_t*>(gray + ((int64_t)frame * grows + ry) * gpitch)[dc] = out[j];
     }
 }
@@ -86,7 +89,8 @@ void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t 
                  const Geom& g, int shift, uint8_t* gray) {
     const int dpr = g.gpitch >> 2;
     const int aligned4 = ((reinterpret_cast<uintptr_t>(bgr) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3u) == 0;
-    dim3 grid((dpr + 255) / 256, (g.grows + GRAY_ROWS_PER_BLOCK - 1) / GRAY_ROWS_PER_BLOCK, n_frames);
+    const int groups = (g.grows + GRAY_ROWS_PER_BLOCK - 1) / GRAY_ROWS_PER_BLOCK;
+    dim3 grid((unsigned)(((int64_t)groups * dpr + 255) / 256), 1, n_frames);
     hipLaunchKernelGGL(gray_kernel, grid, dim3(256), 0, s, bgr, row_stride, frame_stride, g.H, g.W, g.gpitch, g.grows,
                        shift == 15 ? 1 : 0, aligned4, gray);
 }
