@@ -40,6 +40,8 @@ typedef struct stx_params {
     int canny_high;    /* default 150       (passive_checker.py:116) */
     int gray_shift;    /* 14 (default) or 15: fixed-point width of the BGR->gray weights (:100) */
     int fft_h, fft_w;  /* 0,0 (default) = transform the whole frame (:120); else a centred crop */
+    int quality_stats; /* 0 (default); 1 = also fill the frame-quality fields below, which the callers of the
+                          texture path compute per frame (/root/reference/app/main.py:120-123, :209-216) */
 } stx_params;
 
 /* Per-frame result: the five metrics of passive_checker.py:125-131, the per-frame score
@@ -60,6 +62,12 @@ typedef struct stx_metrics {
     uint64_t gray_sum;            /* sum of the gray image */
     uint64_t n_pixels;            /* H*W */
     double fft_sum, fft_sumsq;    /* sum, sum of squares of ln(|F|+1) over all FFT bins */
+    /* frame quality (zero unless stx_params.quality_stats): what the fallback checkers score a frame from */
+    double laplacian_variance;    /* cv2.Laplacian(gray, CV_64F).var()   main.py:120, :209 */
+    double brightness_variance;   /* gray.var()                          main.py:123, :210 */
+    int64_t lap_sum;              /* sum of the 3x3 Laplacian (aperture 1, BORDER_REFLECT_101) */
+    uint64_t lap_sumsq;           /* sum of its squares */
+    uint64_t gray_sumsq;          /* sum of squared gray levels */
 } stx_metrics;
 
 /* Accumulated device time per kernel family, measured with HIP events on the stream
@@ -78,7 +86,7 @@ typedef struct stx_timing {
 #define STX_K_FFT_ROWS 4
 #define STX_K_FFT_COLS 5
 #define STX_K_REDUCE 6
-#define STX_K_SYNTH 7
+#define STX_K_SYNTH 7 /* also counts the optional frame-quality pass */
 
 const char* stx_version(void);
 

@@ -128,6 +128,30 @@ void orc_highpass3(const uint8_t* gray, int h, int w, uint8_t* out) {
         }
 }
 
+/* ------------------------------------------------------------------ frame quality statistics
+ * The fallback checker's per-frame inputs (/root/reference/app/main.py:209-210):
+ *   cv2.Laplacian(gray, cv2.CV_64F).var()  -- aperture 1: kernel [0 1 0; 1 -4 1; 0 1 0],
+ *                                             BORDER_REFLECT_101, exact integers as doubles
+ *   gray.var()                             -- population variance of the gray image
+ * Both variances follow from integer sums. */
+void orc_quality_sums(const uint8_t* gray, int h, int w, int64_t* lap_sum, uint64_t* lap_sumsq, uint64_t* gray_sumsq) {
+    int64_t s = 0;
+    uint64_t q = 0, g2 = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int c = gray[(long)y * w + x];
+            const int l = gray[(long)y * w + reflect101(x - 1, w)], r = gray[(long)y * w + reflect101(x + 1, w)];
+            const int u = gray[(long)reflect101(y - 1, h) * w + x], d = gray[(long)reflect101(y + 1, h) * w + x];
+            const int lap = l + r + u + d - 4 * c;
+            s += lap;
+            q += (uint64_t)((int64_t)lap * lap);
+            g2 += (uint64_t)(c * c);
+        }
+    *lap_sum = s;
+    *lap_sumsq = q;
+    *gray_sumsq = g2;
+}
+
 /* ------------------------------------------------------------------ Gaussian
  * cv2.GaussianBlur(gray, (5,5), 0) at passive_checker.py:111: sigma<=0 with
  * ksize 5 selects the fixed kernel [1 4 6 4 1]/16; the 8-bit path is fixed

@@ -64,6 +64,8 @@ int orc_lbp_uniform(const uint8_t* gray, int h, int w, int P, double R, uint8_t*
                     uint32_t* hist /*P+2 bins*/);
 void orc_highpass3(const uint8_t* gray, int h, int w, uint8_t* out);
 void orc_gauss5(const uint8_t* gray, int h, int w, uint8_t* out);
+/* Laplacian (aperture 1, reflect-101) sum / sum of squares and gray sum of squares: main.py:209-210 */
+void orc_quality_sums(const uint8_t* gray, int h, int w, int64_t* lap_sum, uint64_t* lap_sumsq, uint64_t* gray_sumsq);
 int orc_canny(const uint8_t* gray, int h, int w, int low, int high, uint8_t* edges /*0/255*/,
               uint8_t* nms_map /*may be NULL: 0 none,1 weak,2 strong before hysteresis*/);
 int orc_fft_logmag_stats(const uint8_t* gray, int h, int w, int64_t stride, double* sum, double* sumsq,

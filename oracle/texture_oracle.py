@@ -95,6 +95,8 @@ class COracle:
         L.orc_lbp_uniform.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.POINTER(C.c_uint32)]
         L.orc_highpass3.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
         L.orc_gauss5.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
+        L.orc_quality_sums.argtypes = [_u8p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]
         L.orc_canny.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
         L.orc_fft_logmag_stats.argtypes = [
             _u8p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -142,6 +144,13 @@ class COracle:
         out = np.empty_like(gray)
         self.lib.orc_gauss5(_p(gray), gray.shape[0], gray.shape[1], _p(out))
         return out
+
+    def quality_sums(self, gray: np.ndarray):
+        """(sum, sum of squares) of the 3x3 Laplacian and the sum of squared gray levels (main.py:209-210)."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        s, q, g2 = C.c_int64(), C.c_uint64(), C.c_uint64()
+        self.lib.orc_quality_sums(_p(gray), gray.shape[0], gray.shape[1], C.byref(s), C.byref(q), C.byref(g2))
+        return int(s.value), int(q.value), int(g2.value)
 
     def canny(self, gray: np.ndarray, low: int = 50, high: int = 150):
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
@@ -358,3 +367,47 @@ def np_compute_texture_score(frames, threshold: float = 0.6, **kw) -> dict:
         "detailed_metrics": detailed,
         "message": f"Texture analysis {'passed' if passed else 'failed'} (score: {avg:.3f})",
     }
+
+
+# ---------------------------------------------------------------------------- callers of the path
+def np_quality_sums(gray: np.ndarray):
+    """Independent restatement of the fallback checkers' per-frame inputs (main.py:209-210): the image
+    cv2.Laplacian(gray, CV_64F) (aperture 1: [0 1 0; 1 -4 1; 0 1 0], BORDER_REFLECT_101) as exact integers."""
+    from scipy import ndimage
+    k = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], dtype=np.int64)
+    lap = ndimage.correlate(gray.astype(np.int64), k, mode="mirror")
+    g = gray.astype(np.int64)
+    return int(lap.sum()), int((lap * lap).sum()), int((g * g).sum())
+
+
+def np_quality_variances(gray: np.ndarray):
+    """(Laplacian variance, gray variance) the way the reference gets them: numpy's .var() on the images."""
+    from scipy import ndimage
+    k = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], dtype=np.float64)
+    lap = ndimage.correlate(gray.astype(np.float64), k, mode="mirror")
+    return float(lap.var()), float(gray.var())
+
+
+def np_fallback_check(frames, threshold: float = 0.5) -> dict:
+    """main.py:105-141 on the numpy restatement."""
+    if not frames:
+        return {"passed": False, "average_real_score": 0.0, "message": "No frames to analyze"}
+    scores = []
+    for f in frames[:10]:
+        lv, bv = np_quality_variances(np_gray(np.asarray(f)))
+        scores.append((min(lv / 1000.0, 1.0) + min(bv / 10000.0, 1.0)) / 2.0)
+    avg = sum(scores) / len(scores) if scores else 0.5
+    return {"passed": bool(avg >= threshold), "average_real_score": round(float(avg), 3),
+            "message": "Fallback passive check (basic image quality analysis)"}
+
+
+def np_improved_fallback_base(frames) -> float:
+    """Base score of main.py:188-250 with no face detector: first fifteen frames."""
+    scores = []
+    for f in frames[:15]:
+        g = np_gray(np.asarray(f))
+        lv, bv = np_quality_variances(g)
+        edges, _ = np_canny(g, 50, 150)
+        ed = np.count_nonzero(edges) / edges.size
+        scores.append(min(lv / 500.0, 1.0) * 0.4 + min(bv / 5000.0, 1.0) * 0.3 + min(ed * 20, 1.0) * 0.3)
+    return min(sum(scores) / len(scores), 1.0)

@@ -39,6 +39,7 @@ class StxParams(C.Structure):
         ("gray_shift", C.c_int),
         ("fft_h", C.c_int),
         ("fft_w", C.c_int),
+        ("quality_stats", C.c_int),
     ]
 
 
@@ -60,6 +61,11 @@ class StxMetrics(C.Structure):
         ("n_pixels", C.c_uint64),
         ("fft_sum", C.c_double),
         ("fft_sumsq", C.c_double),
+        ("laplacian_variance", C.c_double),
+        ("brightness_variance", C.c_double),
+        ("lap_sum", C.c_int64),
+        ("lap_sumsq", C.c_uint64),
+        ("gray_sumsq", C.c_uint64),
     ]
 
 

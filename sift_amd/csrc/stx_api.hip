@@ -47,7 +47,7 @@ struct Prepared {
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
-    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, acc, changed, staging;
+    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, qpart, acc, changed, staging;
     FrameAcc* acc_host = nullptr;  // pinned
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
@@ -230,6 +230,21 @@ void finalize(const FrameAcc& a, const Geom& g, int P, stx_metrics* m) {
     m->texture_score = texture_score(*m);
 }
 
+// Population variances of the Laplacian image and of the gray image (main.py:209-210) from exact integer sums.
+void finalize_quality(const FrameAcc& a, const Geom& g, stx_metrics* m) {
+    const uint64_t n = (uint64_t)g.H * (uint64_t)g.W;
+    const double dn = (double)n;
+    m->lap_sum = a.lap_sum;
+    m->lap_sumsq = a.lap_sumsq;
+    m->gray_sumsq = a.gray_sumsq;
+    const __int128 ls = (__int128)a.lap_sum;
+    const unsigned __int128 lnum = (unsigned __int128)n * a.lap_sumsq - (unsigned __int128)(ls * ls);
+    m->laplacian_variance = (double)lnum / (dn * dn);
+    const unsigned __int128 gnum =
+        (unsigned __int128)n * a.gray_sumsq - (unsigned __int128)a.gray_sum * (unsigned __int128)a.gray_sum;
+    m->brightness_variance = (double)gnum / (dn * dn);
+}
+
 int make_geom(stx_ctx* c, int h, int w, const stx_params& p, Geom* g) {
     if (h < 1 || w < 1) return fail(c, STX_ERR_INVALID, "frame height and width must be >= 1");
     if (h > STX_MAX_DIM || w > STX_MAX_DIM) return fail(c, STX_ERR_UNSUPPORTED, "frame larger than 8192 in one dimension");
@@ -393,6 +408,12 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         sp.end();
         if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
     }
+    if (p.quality_stats) {
+        if ((rc = ensure(c, sl.qpart, quality_part_bytes(g, F))) != STX_OK) return rc;
+        Span sp(c, &sl.spans, STX_K_SYNTH, 2, s);
+        launch_quality(s, (const uint8_t*)sl.gray.p, F, g, (unsigned long long*)sl.qpart.p, acc);
+        sp.end();
+    }
     // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
     // changed nothing); finish_chunk() checks the last counter and only then adds more
     if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
@@ -437,7 +458,10 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out) {
         c->tacc.frames += (uint64_t)sl.F;
     }
     if (out)
-        for (int i = 0; i < sl.F; ++i) finalize(sl.acc_host[i], pr.g, pr.p.lbp_points, out + i);
+        for (int i = 0; i < sl.F; ++i) {
+            finalize(sl.acc_host[i], pr.g, pr.p.lbp_points, out + i);
+            if (pr.p.quality_stats) finalize_quality(sl.acc_host[i], pr.g, out + i);
+        }
     return STX_OK;
 }
 
@@ -477,6 +501,7 @@ void stx_default_params(stx_params* p) {
     p->gray_shift = 14;
     p->fft_h = 0;
     p->fft_w = 0;
+    p->quality_stats = 0;
 }
 
 static thread_local std::string g_create_err = "null context";
@@ -529,7 +554,7 @@ int stx_destroy(stx_ctx* c) {
     (void)hipSetDevice(c->device);
     sync_all(c);
     for (Slot& sl : c->slot) {
-        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.acc, &sl.changed, &sl.staging};
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.qpart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);

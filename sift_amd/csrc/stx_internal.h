@@ -19,6 +19,10 @@ struct FrameAcc {
     unsigned long long gray_sum;
     double fft_sum;
     double fft_sumsq;
+    // frame-quality sums (only filled when stx_params.quality_stats is set)
+    long long lap_sum;
+    unsigned long long lap_sumsq;
+    unsigned long long gray_sumsq;
 };
 
 // Geometry of one chunk of equally sized frames in the workspace.
@@ -98,6 +102,10 @@ bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, cons
                           const float2* tw, float2* spec);
 bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
                           const float2* tw, double2* part);
+
+// Laplacian / gray-square sums per frame into acc[] (stx_quality.hip); part holds quality_part_bytes.
+size_t quality_part_bytes(const Geom& g, int n_frames);
+void launch_quality(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, unsigned long long* part, FrameAcc* acc);
 
 void launch_synth(hipStream_t s, uint8_t* bgr, int kind, uint64_t seed, uint32_t video, uint32_t frame0, int n_frames,
                   int h, int w);

@@ -223,6 +223,11 @@ class TextureNoiseDetector:
         """passive_checker.py:133-164: the first ten frames, per-frame score, mean, verdict."""
         head = list(frames[:10])
         recs = self.analyze_frames_raw(head) if head else []
+        return self.result_from_records(recs)
+
+    def result_from_records(self, recs: Sequence[StxMetrics]) -> Dict[str, Any]:
+        """The dict of passive_checker.py:158-164 from per-frame records that a device pass already produced
+        (callers that analysed the same frames for their own statistics reuse the pass)."""
         scores = [float(r.texture_score) for r in recs]
         detailed = [metrics_dict(r) for r in recs]
         avg_score = np.mean(scores) if scores else 0.0

@@ -25,7 +25,7 @@ def test_header_symbols_exported():
 
 
 def test_struct_layout_matches_header():
-    assert C.sizeof(_lib.StxMetrics) == 6 * 8 + 26 * 4 + 8 + 5 * 8 + 2 * 8
+    assert C.sizeof(_lib.StxMetrics) == 6 * 8 + 26 * 4 + 8 + 5 * 8 + 2 * 8 + 5 * 8
     assert C.sizeof(_lib.StxParams) == 40
     assert C.sizeof(_lib.StxTiming) == 8 * 8 + 8 * 8 + 8
 
