@@ -33,7 +33,8 @@ def _floats(r):
     return tuple(getattr(r, k) for k in O.METRIC_KEYS) + (r.texture_score,)
 
 
-@pytest.mark.parametrize("kind,h,w", [("natural", 1080, 1920), ("noise", 720, 1280)])
+@pytest.mark.parametrize("kind,h,w", [("natural", 1080, 1920), ("noise", 720, 1280), ("tie", 541, 963),
+                                      ("step", 383, 1283)])
 def test_full_frame_vs_oracle(ctx, coracle, kind, h, w):
     f = synth_frame(kind, SEED + 2, 1, 7, h, w)
     r = ctx.analyze_frames([f])[0]

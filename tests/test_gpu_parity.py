@@ -47,7 +47,9 @@ def _check_record(r, m, P=8, rel=REL):
 
 
 SIZES = [(1, 1), (1, 7), (5, 1), (2, 2), (3, 3), (5, 7), (24, 31), (33, 65), (64, 64), (45, 77), (80, 80),
-         (100, 130), (128, 192), (67, 200)]
+         (100, 130), (128, 192), (67, 200),
+         # around the 128-pixel stencil tiles, the 32-row strips and the 64-row bitmap words
+         (129, 129), (130, 257), (257, 131), (97, 515), (300, 390)]
 
 
 @pytest.mark.parametrize("kind", KINDS)
