@@ -24,19 +24,21 @@ struct __attribute__((aligned(4))) Bgr4 {
 
 constexpr int GRAY_ROWS_PER_BLOCK = 4;
 
-// grid: x = 256-thread blocks over (group of 4 padded rows, dword column) pairs, z = frame; the pairs are
-// numbered row group major, so narrow frames (crops) fill their workgroups too.
+// grid, wide frames: x = 256-dword column blocks of a padded row, y = groups of 4 padded rows, z = frame;
+// narrow frames (FLAT): x = 256-thread blocks over (row group, dword column) pairs numbered row group
+// major, so that crops fill their workgroups too.
 // A thread converts the same four-pixel column of four consecutive rows: four independent 12-byte
 // loads in flight per lane, and a quarter of the workgroups to dispatch.
+template <bool FLAT>
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ bgr, int64_t row_stride,
                                                    int64_t frame_stride, int H, int W, int gpitch, int grows,
                                                    int shift15, int aligned4, uint8_t* __restrict__ gray) {
     const int frame = blockIdx.z;
     const int dpr = gpitch >> 2;
     const int id = blockIdx.x * 256 + threadIdx.x;
-    const int rgroup = id / dpr;
-    const int dc = id - rgroup * dpr;
-    if (rgroup * GRAY_ROWS_PER_BLOCK >= grows) return;
+    const int rgroup = FLAT ? id / dpr : (int)blockIdx.y;
+    const int dc = FLAT ? id - rgroup * dpr : id;
+    if (dc >= dpr || rgroup * GRAY_ROWS_PER_BLOCK >= grows) return;
     const int x = 4 * dc - GRAY_XOFF;
     const uint8_t* fsrc = bgr + (int64_t)frame * frame_stride;
     const bool fast = aligned4 && x >= 0 && x + 3 < W;
@@ -90,9 +92,15 @@ void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t 
     const int dpr = g.gpitch >> 2;
     const int aligned4 = ((reinterpret_cast<uintptr_t>(bgr) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3u) == 0;
     const int groups = (g.grows + GRAY_ROWS_PER_BLOCK - 1) / GRAY_ROWS_PER_BLOCK;
-    dim3 grid((unsigned)(((int64_t)groups * dpr + 255) / 256), 1, n_frames);
-    hipLaunchKernelGGL(gray_kernel, grid, dim3(256), 0, s, bgr, row_stride, frame_stride, g.H, g.W, g.gpitch, g.grows,
-                       shift == 15 ? 1 : 0, aligned4, gray);
+    if (dpr >= 256) {
+        dim3 grid((dpr + 255) / 256, groups, n_frames);
+        hipLaunchKernelGGL(gray_kernel<false>, grid, dim3(256), 0, s, bgr, row_stride, frame_stride, g.H, g.W, g.gpitch,
+                           g.grows, shift == 15 ? 1 : 0, aligned4, gray);
+    } else {
+        dim3 grid((unsigned)(((int64_t)groups * dpr + 255) / 256), 1, n_frames);
+        hipLaunchKernelGGL(gray_kernel<true>, grid, dim3(256), 0, s, bgr, row_stride, frame_stride, g.H, g.W, g.gpitch,
+                           g.grows, shift == 15 ? 1 : 0, aligned4, gray);
+    }
 }
 
 }  // namespace stx
