@@ -13,6 +13,14 @@ LBP_IMAGES = [
 ]
 LBP_PR = [(8, 1.0), (16, 2.0), (24, 3.0)]
 
+# Adversarial LBP image: pixels drawn (by the synthetic generator's hash) from an alphabet whose differences
+# k hit the good rational approximations of 1 + sqrt(2) (5/2, 12/5, 29/12, 70/29, 169/70).  With the
+# (8,1) bilinear weights 0.70711^2, 0.70711*0.29289, 0.29289^2 that makes many diagonal samples land within
+# 3e-3 .. 2e-4 gray levels of the centre without being exact ties: the cases a sign pre-decision with an
+# error margin must not get wrong.
+LATTICE_ALPHABET = [100, 95, 105, 88, 112, 71, 129, 30, 170, 199, 1]
+LATTICE_SHAPE = (192, 200)
+
 # (kind, h, w) for the FFT statistic goldens (numpy 2.2.6)
 FFT_IMAGES = [
     ("noise", 24, 31), ("natural", 40, 40), ("noise", 64, 64), ("natural", 80, 80), ("step", 90, 120),

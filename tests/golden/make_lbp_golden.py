@@ -20,6 +20,7 @@ from skimage.feature import local_binary_pattern  # noqa: E402
 
 from cases import LBP_IMAGES, LBP_PR, SEED  # noqa: E402
 from sift_amd.synth import synth_frame  # noqa: E402
+from lattice import lattice_image  # noqa: E402
 
 out = {"skimage_version": np.array(skimage.__version__), "numpy_version": np.array(np.__version__)}
 for (P, R) in LBP_PR:
@@ -33,5 +34,8 @@ for idx, (kind, h, w) in enumerate(LBP_IMAGES):
         assert codes.dtype == np.float64 and codes.min() >= 0 and codes.max() <= P + 1
         assert np.all(codes == np.floor(codes))
         out["lbp_%02d_%s_%dx%d_P%d" % (idx, kind, h, w, P)] = codes.astype(np.uint8)
+lat = lattice_image()
+for (P, R) in LBP_PR:
+    out["lbp_lattice_P%d" % P] = local_binary_pattern(lat, P=P, R=R, method="uniform").astype(np.uint8)
 np.savez_compressed(os.path.join(HERE, "lbp_skimage.npz"), **out)
 print("wrote", len(out), "arrays; skimage", skimage.__version__)

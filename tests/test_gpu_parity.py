@@ -92,6 +92,33 @@ def test_lbp_codes_vs_skimage_golden(ctx):
             assert np.array_equal(codes, want), (kind, h, w, P, int((codes != want).sum()))
 
 
+def test_lbp_near_tie_lattice_vs_skimage(ctx, coracle):
+    """The adversarial image of the goldens: many diagonal samples a few 1e-4 gray levels off the centre, i.e.
+    just inside and just outside the error margin of the fixed-point pre-decision."""
+    from lattice import lattice_image
+    gold = np.load(os.path.join(GOLD, "lbp_skimage.npz"))
+    g = lattice_image()
+    p16 = ctx.default_params(); p16.lbp_points = 16; p16.lbp_radius = 2.0
+    p24 = ctx.default_params(); p24.lbp_points = 24; p24.lbp_radius = 3.0
+    settings = ((8, 1.0, None), (16, 2.0, p16), (24, 3.0, p24))
+    bgr = np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))
+    for P, R, prm in settings:
+        _, codes, _ = ctx.debug_planes(bgr, prm)
+        want = gold["lbp_lattice_P%d" % P]
+        assert np.array_equal(codes, want), (P, int((codes != want).sum()))
+    # Embedded at several offsets, so that the same neighbourhoods meet interior and border strips, both pixels
+    # of a lane and every row of a block.  The outcome of an exact tie depends on the pixel's coordinates (the
+    # fp64 weights do), so these are checked against the C oracle, itself pinned by the golden above.
+    for (oy, ox) in ((1, 1), (37, 130), (2, 127)):
+        big = np.full((g.shape[0] + oy + 3, g.shape[1] + ox + 5), 100, np.uint8)
+        big[oy:oy + g.shape[0], ox:ox + g.shape[1]] = g
+        bgr = np.ascontiguousarray(np.repeat(big[..., None], 3, axis=2))
+        for P, R, prm in settings:
+            _, codes, _ = ctx.debug_planes(bgr, prm)
+            want, _ = coracle.lbp(big, P, R)
+            assert np.array_equal(codes, want), (oy, ox, P, int((codes != want).sum()))
+
+
 def test_score_sets_golden(det):
     gold = json.load(open(os.path.join(GOLD, "score_sets.json")))
     for si, (name, kind, n, h, w) in enumerate(SCORE_SETS):
