@@ -33,9 +33,14 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
 // that pass".  From pass 1 on a tile is revisited only if it or one of its eight neighbours
 // changed in the previous pass.  nlines = image width, nwords = words per line, ntiles =
 // 64-line tiles across the image.
+__device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
+                                          int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
+                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half);
+
 // Four independent tiles per workgroup (one per wave): most passes after the first only look at their
 // flags and leave, and then the cost of a pass is the number of workgroups to dispatch.
 constexpr int HYST_WAVES = 4;
+constexpr int HYST_MAX_GRID = 4096;  // workgroups per pass; each walks over the tiles with this stride
 __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
                                                                     const unsigned long long* __restrict__ cand,
                                                                     int nlines, int nwords, int ntiles, int total_tiles,
@@ -43,8 +48,13 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
                                                                     uint32_t* __restrict__ tile_count, uint8_t* tflag,
                                                                     int64_t tflag_half) {
     if (pass > 0 && changed[pass - 1] == 0) return;
-    const int tile_id = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6);
-    if (tile_id >= total_tiles) return;
+    for (int tile_id = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6); tile_id < total_tiles; tile_id += gridDim.x * HYST_WAVES)
+        hyst_tile(strong, cand, nlines, nwords, ntiles, tile_id, changed, pass, tile_count, tflag, tflag_half);
+}
+
+__device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
+                                          int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
+                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half) {
     const int tpf = ntiles * nwords;
     const int frame = tile_id / tpf;
     const int rem = tile_id - frame * tpf;
@@ -198,7 +208,9 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     const int total = (int)half;
-    hipLaunchKernelGGL(hyst_pass_kernel, dim3((total + HYST_WAVES - 1) / HYST_WAVES), dim3(64 * HYST_WAVES), 0, s, strong,
+    int grid = (total + HYST_WAVES - 1) / HYST_WAVES;
+    if (grid > HYST_MAX_GRID) grid = HYST_MAX_GRID;
+    hipLaunchKernelGGL(hyst_pass_kernel, dim3(grid), dim3(64 * HYST_WAVES), 0, s, strong,
                        cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half);
 }
 
