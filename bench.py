@@ -69,6 +69,8 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--kind", default="natural")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-fed", action="store_true",
+                    help="also report the PCIe-inclusive rate from a pinned host batch (never the headline value)")
     ap.add_argument("--pipeline", action="store_true",
                     help="two clips in flight through stx_submit_batch_device / stx_wait instead of one blocking "
                          "call per step (same throughput: the kernels, not the host, bound the step)")
@@ -235,11 +237,31 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, clips[0], nf, h, w, args.cpu_seconds, rows[0])
             result["parity_ok"] = result["cpu_baseline"]["max_rel_diff_vs_gpu"] <= 1e-4
+        if world == 1 and args.host_fed:
+            result["host_fed"] = host_fed(ctx, clips[0], nf, h, w)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def host_fed(ctx, clip, nf: int, h: int, w: int) -> dict:
+    """The same clip fed from page-locked host memory (sift_amd.frames.PinnedFrameBatch): host-to-device copy
+    included, so this is bounded by PCIe, not by the kernels."""
+    from sift_amd.frames import PinnedFrameBatch
+
+    batch = PinnedFrameBatch(ctx, nf, h, w)
+    batch.array[...] = ctx.d2h(clip.data_ptr(), nf * h * w * 3).reshape(nf, h, w, 3)
+    batch.count = nf
+    batch.analyze()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        batch.analyze()
+    dt = (time.perf_counter() - t0) / reps
+    batch.close()
+    return {"frames_per_s": nf / dt, "GB_per_s": nf * h * w * 3 / dt / 1e9, "memory": "pinned", "ms_per_step": dt * 1e3}
 
 
 def cpu_baseline(ctx, clip, nf: int, h: int, w: int, budget_s: float, gpu_rows: np.ndarray) -> dict:
