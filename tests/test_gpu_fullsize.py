@@ -34,7 +34,9 @@ def _floats(r):
 
 
 @pytest.mark.parametrize("kind,h,w", [("natural", 1080, 1920), ("noise", 720, 1280), ("tie", 541, 963),
-                                      ("step", 383, 1283)])
+                                      ("step", 383, 1283),
+                                      # the largest supported extent in each direction (STX_MAX_DIM)
+                                      ("noise", 48, 8192), ("natural", 8192, 40)])
 def test_full_frame_vs_oracle(ctx, coracle, kind, h, w):
     f = synth_frame(kind, SEED + 2, 1, 7, h, w)
     r = ctx.analyze_frames([f])[0]
