@@ -109,6 +109,14 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
         if (hasl) Bl = sb[lb - nlines];
         if (hasr) Br = sb[lb + nlines];
     }
+    if (!__any((S | Lw | Rw) != 0) && (To | Tl | Tr | Bo | Bl | Br) == 0) {
+        // candidates but not one strong pixel in the tile or around it: nothing to grow from (yet)
+        if (lane == 0) {
+            fl_cur[tl * nwords + wx] = 0;
+            tile_count[tbase + tl * nwords + wx] = 0;
+        }
+        return;
+    }
     unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
     unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
     if (lane == 0) { upL = Tl; upR = Tr; }
