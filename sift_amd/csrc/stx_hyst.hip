@@ -37,10 +37,10 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
                                           int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
                                           uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half);
 
-// Four independent tiles per workgroup (one per wave): most passes after the first only look at their
-// flags and leave, and then the cost of a pass is the number of workgroups to dispatch.
+// Four waves per workgroup, each working on tiles of its own.
 constexpr int HYST_WAVES = 4;
-constexpr int HYST_MAX_GRID = 4096;  // workgroups per pass; each walks over the tiles with this stride
+constexpr int HYST_MAX_GRID = 4096;  // workgroups of the first two passes; each walks over the tiles with this stride
+constexpr int HYST_LATER_GRID = 1024;  // the passes after them visit few tiles: fewer workgroups to dispatch
 __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned long long* __restrict__ strong,
                                                                     const unsigned long long* __restrict__ cand,
                                                                     int nlines, int nwords, int ntiles, int total_tiles,
@@ -48,8 +48,43 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
                                                                     uint32_t* __restrict__ tile_count, uint8_t* tflag,
                                                                     int64_t tflag_half) {
     if (pass > 0 && changed[pass - 1] == 0) return;
-    for (int tile_id = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6); tile_id < total_tiles; tile_id += gridDim.x * HYST_WAVES)
-        hyst_tile(strong, cand, nlines, nwords, ntiles, tile_id, changed, pass, tile_count, tflag, tflag_half);
+    const int wave = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * HYST_WAVES;
+    if (pass == 0) {
+        for (int tile_id = wave; tile_id < total_tiles; tile_id += nwaves)
+            hyst_tile(strong, cand, nlines, nwords, ntiles, tile_id, changed, pass, tile_count, tflag, tflag_half);
+        return;
+    }
+    // Later passes touch few tiles.  A wave looks at the flags of all its tiles at once, one tile per lane (the
+    // same tiles it would walk over in pass 0, so that the tiles of a busy region are spread over many waves): a
+    // tile is revisited only if it or one of its eight neighbours changed in the previous pass; the others just
+    // clear their flag.
+    const int lane = threadIdx.x & 63;
+    const int tpf = ntiles * nwords;
+    for (int j0 = 0; j0 * nwaves + wave < total_tiles; j0 += 64) {
+        const int tile_id = (j0 + lane) * nwaves + wave;
+        int f = 0;
+        if (tile_id < total_tiles) {
+            const int frame = tile_id / tpf;
+            const int rem = tile_id - frame * tpf;
+            const int tl = rem / nwords, wx = rem - tl * nwords;
+            const int64_t tbase = (int64_t)frame * tpf;
+            const uint8_t* fl_prev = tflag + (int64_t)((pass - 1) & 1) * tflag_half + tbase;
+#pragma unroll
+            for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int nl = tl + dl, nx = wx + dx;
+                    if (nl >= 0 && nl < ntiles && nx >= 0 && nx < nwords) f |= fl_prev[nl * nwords + nx];
+                }
+            if (!f) tflag[(int64_t)(pass & 1) * tflag_half + tbase + rem] = 0;
+        }
+        unsigned long long todo = __ballot(f != 0);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half);
+        }
+    }
 }
 
 __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
@@ -62,19 +97,6 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
     const int lane = threadIdx.x & 63;
     const int64_t tbase = (int64_t)frame * ntiles * nwords;
     uint8_t* fl_cur = tflag + (int64_t)(pass & 1) * tflag_half + tbase;
-    if (pass > 0) {
-        const uint8_t* fl_prev = tflag + (int64_t)((pass - 1) & 1) * tflag_half + tbase;
-        // lanes 0..8 look at the 3x3 tile neighbourhood
-        int f = 0;
-        if (lane < 9) {
-            const int nl = tl + lane / 3 - 1, nx = wx + lane % 3 - 1;
-            if (nl >= 0 && nl < ntiles && nx >= 0 && nx < nwords) f = fl_prev[nl * nwords + nx];
-        }
-        if (!__any(f != 0)) {
-            if (lane == 0) fl_cur[tl * nwords + wx] = 0;
-            return;
-        }
-    }
     const int ln = tl * 64 + lane;
     // maps are stored [frame][word][line]: the 64 lines of a tile are contiguous
     unsigned long long* sb = strong + ((int64_t)frame * nwords + wx) * nlines;
@@ -217,7 +239,8 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     const int total = (int)half;
     int grid = (total + HYST_WAVES - 1) / HYST_WAVES;
-    if (grid > HYST_MAX_GRID) grid = HYST_MAX_GRID;
+    const int cap = pass <= 1 ? HYST_MAX_GRID : HYST_LATER_GRID;
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(hyst_pass_kernel, dim3(grid), dim3(64 * HYST_WAVES), 0, s, strong,
                        cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half);
 }
