@@ -150,6 +150,17 @@ int stx_pinned_free(stx_ctx* ctx, void* p);
 int stx_memcpy_d2h(stx_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int stx_memcpy_h2d(stx_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 
+/* Frame preparation of the CNN branch: replaces PassiveChecker._preprocess_frame
+ * (app/passive_checker.py:393-418), called per frame at :432 from the loop at :473 -- BGR -> RGB, cv2.resize to
+ * (out_w, out_h) with the default bilinear interpolation (OpenCV's 8-bit fixed-point arithmetic, bit for bit),
+ * float32 / 255, planes first.  out holds n_frames x 3 x out_h x out_w floats (R, G, B planes per frame).
+ * The reference's input size is (80, 80) (passive_checker.py:355).  The _device form takes frames and output
+ * in device memory. */
+int stx_preprocess_frames(stx_ctx* ctx, const uint8_t* const* frames, int n_frames, int h, int w, int64_t row_stride,
+                          int out_h, int out_w, float* out_host);
+int stx_preprocess_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                int64_t frame_stride, int out_h, int out_w, float* out_dev);
+
 /* Frames per internal chunk (0 = choose from the frame size: up to 2 GiB of intermediates per
  * in-flight chunk, two chunks in flight). */
 int stx_set_chunk_frames(stx_ctx* ctx, int frames);

@@ -411,3 +411,65 @@ def np_improved_fallback_base(frames) -> float:
         ed = np.count_nonzero(edges) / edges.size
         scores.append(min(lv / 500.0, 1.0) * 0.4 + min(bv / 5000.0, 1.0) * 0.3 + min(ed * 20, 1.0) * 0.3)
     return min(sum(scores) / len(scores), 1.0)
+
+
+# ---------------------------------------------------------------------------- frame preparation (CNN branch)
+def _resize_taps(src: int, dst: int, horizontal: bool):
+    """Tap positions and 11-bit weights of cv::resize(INTER_LINEAR) along one axis (8-bit images).
+    coordinate = (d + 0.5) * scale - 0.5 rounded to float32; weights saturate_cast<short>(w * 2048);
+    columns outside the image collapse onto the border column with weight 2048, rows are clamped and
+    keep their weights."""
+    scale = 1.0 / (float(dst) / float(src))
+    i0 = np.zeros(dst, np.int64)
+    i1 = np.zeros(dst, np.int64)
+    w0 = np.zeros(dst, np.int64)
+    w1 = np.zeros(dst, np.int64)
+    for d in range(dst):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        if horizontal:
+            if s < 0:
+                f, s = np.float32(0), 0
+            if s + 1 >= src:
+                f, s = np.float32(0), src - 1
+                t = s
+            else:
+                t = s + 1
+        else:
+            t = min(max(s + 1, 0), src - 1)
+            s = min(max(s, 0), src - 1)
+        i0[d], i1[d] = s, t
+        w0[d] = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))
+        w1[d] = int(np.rint(f * np.float32(2048)))
+    return i0, i1, w0, w1
+
+
+def np_resize_linear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv2.resize(img, (out_w, out_h)) for uint8 H x W x C images, default interpolation
+    (passive_checker.py:407).  Restated from OpenCV's algorithm; no OpenCV in this image to pin it."""
+    h, w = img.shape[:2]
+    a = img.astype(np.int64)
+    sx, sy = 1.0 / (float(out_w) / w), 1.0 / (float(out_h) / h)
+    eps = np.finfo(np.float64).eps
+    if abs(sx - 2.0) < eps and abs(sy - 2.0) < eps:
+        # exact 2:1 reduction: OpenCV switches to the 2x2 area average
+        s = a[0:2 * out_h:2, 0:2 * out_w:2] + a[0:2 * out_h:2, 1:2 * out_w:2] + \
+            a[1:2 * out_h:2, 0:2 * out_w:2] + a[1:2 * out_h:2, 1:2 * out_w:2]
+        return ((s + 2) >> 2).astype(np.uint8)
+    xi0, xi1, xw0, xw1 = _resize_taps(w, out_w, True)
+    yi0, yi1, yw0, yw1 = _resize_taps(h, out_h, False)
+    shp = (1, out_w) + (1,) * (a.ndim - 2)
+    rows = a[:, xi0] * xw0.reshape(shp) + a[:, xi1] * xw1.reshape(shp)  # [h][out_w][C]
+    shp = (out_h, 1) + (1,) * (a.ndim - 2)
+    s0, s1 = rows[yi0], rows[yi1]
+    v = (((yw0.reshape(shp) * (s0 >> 4)) >> 16) + ((yw1.reshape(shp) * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def np_preprocess_frame(frame: np.ndarray, input_size=(80, 80)) -> np.ndarray:
+    """passive_checker.py:393-418 without the torch wrapper: [1][3][H][W] float32."""
+    rgb = np.asarray(frame)[:, :, ::-1]
+    resized = np_resize_linear_u8(rgb, input_size[1], input_size[0])
+    normalized = resized.astype(np.float32) / 255.0
+    return np.transpose(normalized, (2, 0, 1))[None]

@@ -22,7 +22,7 @@ EXPORTS = (
     "stx_max_async_frames", "stx_score_summary",
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
     "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing",
-    "stx_get_timing",
+    "stx_get_timing", "stx_preprocess_frames", "stx_preprocess_batch_device",
 )
 
 
@@ -85,6 +85,13 @@ def load() -> C.CDLL:
         raise StxError(
             f"{LIB_PATH} is missing: build it with `make -C sift_amd/csrc` (or __graft_entry__.build()); "
             "there is no CPU fallback")
+    # PyTorch's wheels carry their own copy of the HIP runtime.  A process can hold the GPU through one
+    # runtime only: if this library pulled in the system's copy first, torch.cuda would later find no device.
+    # Importing torch first makes both use the copy torch ships.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     u8p = C.c_void_p
     L.stx_version.restype = C.c_char_p
@@ -118,5 +125,9 @@ def load() -> C.CDLL:
     L.stx_set_concurrency.argtypes = [C.c_void_p, C.c_int]
     L.stx_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.stx_get_timing.argtypes = [C.c_void_p, C.POINTER(StxTiming), C.c_int]
+    L.stx_preprocess_frames.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64,
+                                        C.c_int, C.c_int, C.c_void_p]
+    L.stx_preprocess_batch_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                              C.c_int, C.c_int, C.c_void_p]
     _lib = L
     return L

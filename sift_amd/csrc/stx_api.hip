@@ -72,7 +72,7 @@ struct stx_ctx {
     hipStream_t stream_fft = nullptr;  // FFT rows + columns
     std::string err;
     Slot slot[N_SLOTS];
-    DevBuf codes, plane;
+    DevBuf codes, plane, taps, prep_out;
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
     bool concurrent_fft = true;
@@ -566,6 +566,8 @@ int stx_destroy(stx_ctx* c) {
     }
     if (c->codes.p) (void)hipFree(c->codes.p);
     if (c->plane.p) (void)hipFree(c->plane.p);
+    if (c->taps.p) (void)hipFree(c->taps.p);
+    if (c->prep_out.p) (void)hipFree(c->prep_out.p);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -767,6 +769,79 @@ int stx_debug_planes(stx_ctx* c, const uint8_t* bgr, int h, int w, int64_t row_s
         HIPCHK(c, hipMemcpyAsync(edges_out, c->plane.p, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return STX_OK;
+}
+
+// ---- frame preparation for the CNN branch (passive_checker.py:393-418)
+static int preprocess_common(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                             int64_t frame_stride, int out_h, int out_w, float* out_dev) {
+    std::vector<uint8_t> host(preprocess_tap_bytes(out_w) + preprocess_tap_bytes(out_h));
+    preprocess_fill_taps(h, w, out_h, out_w, host.data(), host.data() + preprocess_tap_bytes(out_w));
+    int rc;
+    if ((rc = ensure(c, c->taps, host.size())) != STX_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->taps.p, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host is a local
+    launch_preprocess(c->stream, bgr_dev, row_stride, frame_stride, n_frames, out_h, out_w, c->taps.p,
+                      (const uint8_t*)c->taps.p + preprocess_tap_bytes(out_w), preprocess_is_area2(h, w, out_h, out_w),
+                      out_dev);
+    HIPCHK(c, hipGetLastError());
+    return STX_OK;
+}
+
+static int preprocess_check(stx_ctx* c, int n_frames, int h, int w, int64_t row_stride, int out_h, int out_w) {
+    if (n_frames < 0 || n_frames > 65535) return fail(c, STX_ERR_INVALID, "n_frames out of range");
+    if (h < 1 || w < 1 || h > 8192 || w > 8192) return fail(c, STX_ERR_INVALID, "frame size out of range (1..8192)");
+    if (out_h < 1 || out_w < 1 || out_h > 4096 || out_w > 4096) return fail(c, STX_ERR_INVALID, "output size out of range (1..4096)");
+    if (row_stride < (int64_t)3 * w) return fail(c, STX_ERR_INVALID, "row stride smaller than 3*w");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
+    return STX_OK;
+}
+
+int stx_preprocess_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                int64_t frame_stride, int out_h, int out_w, float* out_dev) {
+    if (!c) return STX_ERR_INVALID;
+    int rc = preprocess_check(c, n_frames, h, w, row_stride, out_h, out_w);
+    if (rc != STX_OK) return rc;
+    if (n_frames == 0) return STX_OK;
+    if (!bgr_dev || !out_dev) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (n_frames > 1 && frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "frame stride smaller than the frame");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = preprocess_common(c, bgr_dev, n_frames, h, w, row_stride, frame_stride, out_h, out_w, out_dev)) != STX_OK)
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return STX_OK;
+}
+
+int stx_preprocess_frames(stx_ctx* c, const uint8_t* const* frames, int n_frames, int h, int w, int64_t row_stride,
+                          int out_h, int out_w, float* out_host) {
+    if (!c) return STX_ERR_INVALID;
+    int rc = preprocess_check(c, n_frames, h, w, row_stride, out_h, out_w);
+    if (rc != STX_OK) return rc;
+    if (n_frames == 0) return STX_OK;
+    if (!frames || !out_host) return fail(c, STX_ERR_INVALID, "null pointer");
+    for (int f = 0; f < n_frames; ++f)
+        if (!frames[f]) return fail(c, STX_ERR_INVALID, "null frame pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
+    const size_t plane = (size_t)3 * out_h * out_w;
+    // frames go through the staging buffer a bounded number at a time
+    const int per = std::max<int64_t>(1, std::min<int64_t>(n_frames, ((int64_t)256 << 20) / (dpitch * h)));
+    Slot& sl = c->slot[0];
+    if ((rc = ensure(c, sl.staging, (size_t)dpitch * h * per)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->prep_out, plane * per * sizeof(float))) != STX_OK) return rc;
+    for (int f0 = 0; f0 < n_frames; f0 += per) {
+        const int F = std::min(per, n_frames - f0);
+        for (int f = 0; f < F; ++f)
+            HIPCHK(c, hipMemcpy2DAsync((uint8_t*)sl.staging.p + (size_t)f * dpitch * h, (size_t)dpitch, frames[f0 + f],
+                                       (size_t)row_stride, (size_t)3 * w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        if ((rc = preprocess_common(c, (const uint8_t*)sl.staging.p, F, h, w, dpitch, dpitch * h, out_h, out_w,
+                                    (float*)c->prep_out.p)) != STX_OK)
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(out_host + (size_t)f0 * plane, c->prep_out.p, plane * F * sizeof(float),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return STX_OK;
 }
 

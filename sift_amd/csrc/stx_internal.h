@@ -107,6 +107,14 @@ bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const
 size_t quality_part_bytes(const Geom& g, int n_frames);
 void launch_quality(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, unsigned long long* part, FrameAcc* acc);
 
+// Frame preparation of the CNN branch (stx_preprocess.hip): bilinear resize in cv::resize's fixed point,
+// BGR -> RGB planes, / 255.  The tap tables are filled on the host and copied to the device by the caller.
+size_t preprocess_tap_bytes(int n);
+void preprocess_fill_taps(int h, int w, int out_h, int out_w, void* xt_host, void* yt_host);
+bool preprocess_is_area2(int h, int w, int out_h, int out_w);
+void launch_preprocess(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
+                       int out_h, int out_w, const void* xt, const void* yt, bool area2, float* out);
+
 void launch_synth(hipStream_t s, uint8_t* bgr, int kind, uint64_t seed, uint32_t video, uint32_t frame0, int n_frames,
                   int h, int w);
 

@@ -54,13 +54,10 @@ class TextureContext:
         self.lib.stx_default_params(C.byref(p))
         return p
 
-    # ---- host frames
-    def analyze_frames(self, frames: Sequence[np.ndarray], params: Optional[StxParams] = None):
-        """All frames must share one shape [H][W][3] uint8.  Returns a ctypes array of StxMetrics."""
+    @staticmethod
+    def _frame_ptrs(frames: Sequence[np.ndarray]):
+        """Pointers to n same-shaped uint8 BGR frames with one common row stride (copies those that differ)."""
         n = len(frames)
-        out = (StxMetrics * max(n, 1))()
-        if n == 0:
-            return out
         h, w, ch = frames[0].shape
         if ch != 3:
             raise ValueError("frames must be H x W x 3 (BGR)")
@@ -81,6 +78,16 @@ class TextureContext:
                     raise ValueError("frames with different row strides in one call")
             keep.append(f)
             ptrs[i] = f.ctypes.data
+        return keep, ptrs, h, w, stride
+
+    # ---- host frames
+    def analyze_frames(self, frames: Sequence[np.ndarray], params: Optional[StxParams] = None):
+        """All frames must share one shape [H][W][3] uint8.  Returns a ctypes array of StxMetrics."""
+        n = len(frames)
+        out = (StxMetrics * max(n, 1))()
+        if n == 0:
+            return out
+        keep, ptrs, h, w, stride = self._frame_ptrs(frames)
         rc = self.lib.stx_analyze_frames(self.handle, ptrs, n, h, w, stride, C.byref(params) if params is not None else None, out)
         self._check(rc, "stx_analyze_frames")
         return out
@@ -123,6 +130,25 @@ class TextureContext:
 
     def max_async_frames(self, h: int, w: int) -> int:
         return int(self.lib.stx_max_async_frames(self.handle, h, w))
+
+    # ---- frame preparation of the CNN branch
+    def preprocess_frames(self, frames: Sequence[np.ndarray], out_h: int = 80, out_w: int = 80) -> np.ndarray:
+        """[N][3][out_h][out_w] float32 (RGB planes in 0..1) from N same-shaped BGR frames."""
+        n = len(frames)
+        out = np.empty((n, 3, out_h, out_w), np.float32)
+        if n == 0:
+            return out
+        keep, ptrs, h, w, stride = self._frame_ptrs(frames)
+        rc = self.lib.stx_preprocess_frames(self.handle, ptrs, n, h, w, stride, out_h, out_w, out.ctypes.data)
+        self._check(rc, "stx_preprocess_frames")
+        return out
+
+    def preprocess_device(self, dev_ptr: int, n: int, h: int, w: int, out_ptr: int, out_h: int = 80, out_w: int = 80,
+                          row_stride: Optional[int] = None, frame_stride: Optional[int] = None):
+        rs = 3 * w if row_stride is None else row_stride
+        fs = rs * h if frame_stride is None else frame_stride
+        rc = self.lib.stx_preprocess_batch_device(self.handle, dev_ptr, n, h, w, rs, fs, out_h, out_w, out_ptr)
+        self._check(rc, "stx_preprocess_batch_device")
 
     def synth_device(self, dev_ptr: int, kind: int, seed: int, video: int, frame0: int, n: int, h: int, w: int):
         self._check(self.lib.stx_synth_device(self.handle, dev_ptr, kind, seed, video, frame0, n, h, w), "stx_synth_device")
