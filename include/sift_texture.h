@@ -150,6 +150,37 @@ int stx_pinned_free(stx_ctx* ctx, void* p);
 int stx_memcpy_d2h(stx_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int stx_memcpy_h2d(stx_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 
+/* Extended per-frame statistics.  No counterpart in the reference: they are the multi-scale additions
+ * (LBP at further radii, Sobel gradient statistics on the images cv2.Canny builds at
+ * app/passive_checker.py:116, 8x8 blockiness) and are only reported here, never in the reference's dict.
+ * Integer fields are exact; the floats derive from them on the host.
+ *   mag = |gx| + |gy| (Sobel 3x3, replicated borders): sobel_sum, sobel_sumsq, sobel_strong = count(mag > canny_high)
+ *   block_sums[0..3] = sum |g(y,x)-g(y,x-1)| over x%8==0 (x>=8) / over the other x>=1, then the same for rows;
+ *   block_counts[] = how many differences each sum holds
+ *   blockiness = mean difference across 8-pixel boundaries / (mean difference inside blocks + 1e-10)
+ *   edge_consistency = Canny edge pixels / sobel_strong (0 when there is none) */
+typedef struct stx_extended {
+    double sobel_mean;
+    double sobel_std;
+    double strong_gradient_fraction;
+    double edge_consistency;
+    double blockiness;
+    uint64_t sobel_sum;
+    uint64_t sobel_sumsq;
+    uint64_t block_sums[4];
+    uint64_t block_counts[4];
+    uint32_t sobel_strong;
+    uint32_t reserved;
+    uint32_t lbp_hist_p16r2[STX_LBP_MAX_BINS]; /* uniform LBP histogram at P=16, R=2 (18 bins used) */
+    uint32_t lbp_hist_p24r3[STX_LBP_MAX_BINS]; /* ... at P=24, R=3 (26 bins) */
+} stx_extended;
+
+/* stx_analyze_frames / stx_analyze_batch_device plus one stx_extended record per frame. */
+int stx_analyze_extended_frames(stx_ctx* ctx, const uint8_t* const* frames, int n_frames, int h, int w, int64_t row_stride,
+                                const stx_params* params, stx_metrics* out, stx_extended* ext);
+int stx_analyze_extended_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                      int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext);
+
 /* Frame preparation of the CNN branch: replaces PassiveChecker._preprocess_frame
  * (app/passive_checker.py:393-418), called per frame at :432 from the loop at :473 -- BGR -> RGB, cv2.resize to
  * (out_w, out_h) with the default bilinear interpolation (OpenCV's 8-bit fixed-point arithmetic, bit for bit),

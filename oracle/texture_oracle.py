@@ -473,3 +473,42 @@ def np_preprocess_frame(frame: np.ndarray, input_size=(80, 80)) -> np.ndarray:
     resized = np_resize_linear_u8(rgb, input_size[1], input_size[0])
     normalized = resized.astype(np.float32) / 255.0
     return np.transpose(normalized, (2, 0, 1))[None]
+
+
+# ---------------------------------------------------------------------------- extended statistics
+def np_extended_sums(gray: np.ndarray, high: int = 150) -> dict:
+    """Exact integer sums behind the extended statistics (no counterpart in the reference; the definitions are
+    this project's own): Sobel L1 magnitude with replicated borders -- the images cv2.Canny builds at
+    passive_checker.py:116 -- and absolute neighbour differences split into 8-pixel block boundaries and block
+    interiors, horizontally and vertically."""
+    from scipy import ndimage
+    g = gray.astype(np.int64)
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=np.int64)
+    gx = ndimage.correlate(g, kx, mode="nearest")
+    gy = ndimage.correlate(g, kx.T, mode="nearest")
+    mag = np.abs(gx) + np.abs(gy)
+    h, w = g.shape
+    dh = np.abs(g[:, 1:] - g[:, :-1])  # column x = 1..w-1
+    dv = np.abs(g[1:, :] - g[:-1, :])
+    xb = (np.arange(1, w) % 8) == 0
+    yb = (np.arange(1, h) % 8) == 0
+    return {
+        "sobel_sum": int(mag.sum()), "sobel_sumsq": int((mag * mag).sum()), "sobel_strong": int((mag > high).sum()),
+        "block_sums": [int(dh[:, xb].sum()), int(dh[:, ~xb].sum()), int(dv[yb, :].sum()), int(dv[~yb, :].sum())],
+        "block_counts": [int(h * xb.sum()), int(h * (~xb).sum()), int(w * yb.sum()), int(w * (~yb).sum())],
+    }
+
+
+def np_extended_stats(gray: np.ndarray, edge_count: int, high: int = 150) -> dict:
+    s = np_extended_sums(gray, high)
+    n = gray.size
+    mean = s["sobel_sum"] / n
+    var = (n * s["sobel_sumsq"] - s["sobel_sum"] ** 2) / (n * n)
+    ne = s["block_counts"][0] + s["block_counts"][2]
+    ni = s["block_counts"][1] + s["block_counts"][3]
+    me = (s["block_sums"][0] + s["block_sums"][2]) / ne if ne else 0.0
+    mi = (s["block_sums"][1] + s["block_sums"][3]) / ni if ni else 0.0
+    s.update(sobel_mean=mean, sobel_std=float(np.sqrt(var)), strong_gradient_fraction=s["sobel_strong"] / n,
+             edge_consistency=(edge_count / s["sobel_strong"]) if s["sobel_strong"] else 0.0,
+             blockiness=me / (mi + 1e-10))
+    return s

@@ -23,6 +23,7 @@ EXPORTS = (
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
     "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing",
     "stx_get_timing", "stx_preprocess_frames", "stx_preprocess_batch_device",
+    "stx_analyze_extended_frames", "stx_analyze_extended_batch_device",
 )
 
 
@@ -66,6 +67,24 @@ class StxMetrics(C.Structure):
         ("lap_sum", C.c_int64),
         ("lap_sumsq", C.c_uint64),
         ("gray_sumsq", C.c_uint64),
+    ]
+
+
+class StxExtended(C.Structure):
+    _fields_ = [
+        ("sobel_mean", C.c_double),
+        ("sobel_std", C.c_double),
+        ("strong_gradient_fraction", C.c_double),
+        ("edge_consistency", C.c_double),
+        ("blockiness", C.c_double),
+        ("sobel_sum", C.c_uint64),
+        ("sobel_sumsq", C.c_uint64),
+        ("block_sums", C.c_uint64 * 4),
+        ("block_counts", C.c_uint64 * 4),
+        ("sobel_strong", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("lbp_hist_p16r2", C.c_uint32 * LBP_MAX_BINS),
+        ("lbp_hist_p24r3", C.c_uint32 * LBP_MAX_BINS),
     ]
 
 
@@ -129,5 +148,7 @@ def load() -> C.CDLL:
                                         C.c_int, C.c_int, C.c_void_p]
     L.stx_preprocess_batch_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                               C.c_int, C.c_int, C.c_void_p]
+    L.stx_analyze_extended_frames.argtypes = L.stx_analyze_frames.argtypes + [C.POINTER(StxExtended)]
+    L.stx_analyze_extended_batch_device.argtypes = L.stx_analyze_batch.argtypes + [C.POINTER(StxExtended)]
     _lib = L
     return L

@@ -42,12 +42,14 @@ struct Prepared {
     FftPlan plan_w, plan_h;
     float2 *tw_w, *tw_h;
     LbpOffsets off;
+    bool ext = false;        // extended statistics requested
+    LbpOffsets off2, off3;   // their extra LBP radii: (16, 2) and (24, 3)
 };
 
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
-    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, qpart, acc, changed, staging;
+    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, qpart, xpart, acc, changed, staging;
     FrameAcc* acc_host = nullptr;  // pinned
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
@@ -414,6 +416,20 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         launch_quality(s, (const uint8_t*)sl.gray.p, F, g, (unsigned long long*)sl.qpart.p, acc);
         sp.end();
     }
+    if (pr.ext) {
+        if ((rc = ensure(c, sl.xpart, extended_part_bytes(g, F))) != STX_OK) return rc;
+        if ((rc = ensure(c, sl.lpart, lbp_generic_part_bytes(g, F))) != STX_OK) return rc;
+        {
+            Span sp(c, &sl.spans, STX_K_SYNTH, 2, s);
+            launch_extended(s, (const uint8_t*)sl.gray.p, F, g, p.canny_high, (unsigned long long*)sl.xpart.p, acc);
+            sp.end();
+        }
+        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 4, s);
+        const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, 16, pr.off2, (uint32_t*)sl.lpart.p, acc, nullptr, 1) &&
+                        launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, 24, pr.off3, (uint32_t*)sl.lpart.p, acc, nullptr, 2);
+        sp.end();
+        if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
+    }
     // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
     // changed nothing); finish_chunk() checks the last counter and only then adds more
     if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
@@ -440,7 +456,37 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     return queue_results(c, sl, pr);
 }
 
-int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out) {
+// Means, deviations and ratios of the extended statistics from their exact integer sums.
+void finalize_extended(const FrameAcc& a, const Geom& g, stx_extended* x) {
+    memset(x, 0, sizeof(*x));
+    const uint64_t n = (uint64_t)g.H * (uint64_t)g.W;
+    const double dn = (double)n;
+    x->sobel_sum = a.sobel_sum;
+    x->sobel_sumsq = a.sobel_sumsq;
+    x->sobel_strong = a.sobel_strong;
+    for (int k = 0; k < STX_LBP_MAX_BINS; ++k) {
+        x->lbp_hist_p16r2[k] = a.lbp_hist2[k];
+        x->lbp_hist_p24r3[k] = a.lbp_hist3[k];
+    }
+    const uint64_t hb = (uint64_t)((g.W - 1) / 8), vb = (uint64_t)((g.H - 1) / 8);
+    x->block_counts[0] = (uint64_t)g.H * hb;
+    x->block_counts[1] = (uint64_t)g.H * (uint64_t)(g.W - 1) - x->block_counts[0];
+    x->block_counts[2] = (uint64_t)g.W * vb;
+    x->block_counts[3] = (uint64_t)g.W * (uint64_t)(g.H - 1) - x->block_counts[2];
+    for (int k = 0; k < 4; ++k) x->block_sums[k] = a.blk[k];
+    x->sobel_mean = (double)a.sobel_sum / dn;
+    const unsigned __int128 num =
+        (unsigned __int128)n * a.sobel_sumsq - (unsigned __int128)a.sobel_sum * (unsigned __int128)a.sobel_sum;
+    x->sobel_std = sqrt((double)num / (dn * dn));
+    x->strong_gradient_fraction = (double)a.sobel_strong / dn;
+    x->edge_consistency = a.sobel_strong ? (double)a.edge_count / (double)a.sobel_strong : 0.0;
+    const uint64_t ne = x->block_counts[0] + x->block_counts[2], ni = x->block_counts[1] + x->block_counts[3];
+    const double me = ne ? (double)(a.blk[0] + a.blk[2]) / (double)ne : 0.0;
+    const double mi = ni ? (double)(a.blk[1] + a.blk[3]) / (double)ni : 0.0;
+    x->blockiness = me / (mi + 1e-10);
+}
+
+int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx_extended* ext = nullptr) {
     HIPCHK(c, hipEventSynchronize(sl.done));
     while (*sl.changed_host != 0) {
         // rare: long contours still growing after the first batch of passes
@@ -461,12 +507,13 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out) {
         for (int i = 0; i < sl.F; ++i) {
             finalize(sl.acc_host[i], pr.g, pr.p.lbp_points, out + i);
             if (pr.p.quality_stats) finalize_quality(sl.acc_host[i], pr.g, out + i);
+            if (ext) finalize_extended(sl.acc_host[i], pr.g, ext + i);
         }
     return STX_OK;
 }
 
 int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_t row_stride, int64_t frame_stride,
-                        const Prepared& pr, stx_metrics* out) {
+                        const Prepared& pr, stx_metrics* out, stx_extended* ext = nullptr) {
     const int chunk = pick_chunk(c, pr.g, n_frames);
     int prev_slot = -1, prev_f0 = 0, k = 0;
     for (int f0 = 0; f0 < n_frames; f0 += chunk, ++k) {
@@ -474,7 +521,7 @@ int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_
         Slot& sl = c->slot[k % N_SLOTS];
         ChunkOpts o;
         int rc = enqueue_chunk(c, sl, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr, o);
-        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0, ext ? ext + prev_f0 : nullptr);
         if (rc != STX_OK) {
             sync_all(c);
             return rc;
@@ -482,7 +529,13 @@ int analyze_device_impl(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int64_
         prev_slot = k % N_SLOTS;
         prev_f0 = f0;
     }
-    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0, ext ? ext + prev_f0 : nullptr);
+    return STX_OK;
+}
+
+int prepare_extended(stx_ctx* c, Prepared* pr) {
+    pr->ext = true;
+    if (lbp_offsets(16, 2.0, &pr->off2) != 0 || lbp_offsets(24, 3.0, &pr->off3) != 0) return fail(c, STX_ERR_INVALID, "bad lbp_points");
     return STX_OK;
 }
 
@@ -554,7 +607,7 @@ int stx_destroy(stx_ctx* c) {
     (void)hipSetDevice(c->device);
     sync_all(c);
     for (Slot& sl : c->slot) {
-        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.qpart, &sl.acc, &sl.changed, &sl.staging};
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.qpart, &sl.xpart, &sl.acc, &sl.changed, &sl.staging};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);
@@ -594,6 +647,22 @@ int stx_analyze_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, i
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
     return analyze_device_impl(c, bgr_dev, n_frames, row_stride, frame_stride, pr, out);
+}
+
+int stx_analyze_extended_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                      int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext) {
+    if (!c) return STX_ERR_INVALID;
+    if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
+    if (n_frames == 0) return STX_OK;
+    if (!bgr_dev || !out || !ext) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
+    Prepared pr;
+    int rc = prepare(c, h, w, params, &pr);
+    if (rc != STX_OK) return rc;
+    if ((rc = prepare_extended(c, &pr)) != STX_OK) return rc;
+    return analyze_device_impl(c, bgr_dev, n_frames, row_stride, frame_stride, pr, out, ext);
 }
 
 int stx_max_async_frames(stx_ctx* c, int h, int w) {
@@ -641,7 +710,8 @@ int stx_wait(stx_ctx* c, int ticket) {
 }
 
 static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* const* list, int n_frames, int h, int w,
-                               int64_t row_stride, int64_t frame_stride, const stx_params* params, stx_metrics* out) {
+                               int64_t row_stride, int64_t frame_stride, const stx_params* params, stx_metrics* out,
+                               stx_extended* ext = nullptr) {
     if (!c) return STX_ERR_INVALID;
     if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
     if (n_frames == 0) return STX_OK;
@@ -651,6 +721,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
     Prepared pr;
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
+    if (ext && (rc = prepare_extended(c, &pr)) != STX_OK) return rc;
     // device staging: rows padded to a multiple of 4 bytes so the gray kernel's dword path applies
     const int64_t dpitch = ((int64_t)3 * w + 3) & ~(int64_t)3;
     const int64_t dframe = dpitch * h;
@@ -679,7 +750,7 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
         if (rc != STX_OK) break;
         ChunkOpts o;
         rc = enqueue_chunk(c, sl, (const uint8_t*)sl.staging.p, dpitch, dframe, F, pr, o);
-        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+        if (rc == STX_OK && prev_slot >= 0) rc = finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0, ext ? ext + prev_f0 : nullptr);
         if (rc != STX_OK) break;
         prev_slot = k % N_SLOTS;
         prev_f0 = f0;
@@ -688,8 +759,14 @@ static int analyze_host_common(stx_ctx* c, const uint8_t* base, const uint8_t* c
         sync_all(c);
         return rc;
     }
-    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0);
+    if (prev_slot >= 0) return finish_chunk(c, c->slot[prev_slot], pr, out + prev_f0, ext ? ext + prev_f0 : nullptr);
     return STX_OK;
+}
+
+int stx_analyze_extended_frames(stx_ctx* c, const uint8_t* const* frames, int n_frames, int h, int w, int64_t row_stride,
+                                const stx_params* params, stx_metrics* out, stx_extended* ext) {
+    if (c && n_frames > 0 && !ext) return fail(c, STX_ERR_INVALID, "null pointer");
+    return analyze_host_common(c, nullptr, frames, n_frames, h, w, row_stride, 0, params, out, ext);
 }
 
 int stx_analyze_batch(stx_ctx* c, const uint8_t* bgr, int n_frames, int h, int w, int64_t row_stride,

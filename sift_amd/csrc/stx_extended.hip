@@ -1,0 +1,110 @@
+// Extended per-frame statistics that the reference does not compute (no counterpart in
+// /root/reference/app/passive_checker.py): gradient statistics on the Sobel images that cv2.Canny
+// builds at passive_checker.py:116, and an 8x8 blockiness measure of the kind used to detect JPEG /
+// video-codec block structure.  They are only reported through the extended entry points and never
+// alter the reference's result dict.
+//
+// All of it is exact integer work on the gray plane, one streaming pass:
+//   mag(y,x)  = |gx| + |gy|, Sobel 3x3 with replicated borders        -> sum, sum of squares,
+//               count(mag > canny_high)
+//   dh(y,x)   = |g(y,x) - g(y,x-1)|, x >= 1: "boundary" when x % 8 == 0, else "interior"
+//   dv(y,x)   = |g(y,x) - g(y-1,x)|, y >= 1: likewise with y
+// A wave covers 64 columns of a row, i.e. eight 8-pixel blocks: the boundary lanes are lane % 8 == 0,
+// and the per-wave sums come from one cross-lane reduction per statistic at the end.
+#include "stx_internal.h"
+
+namespace stx {
+
+constexpr int X_ROWS = 4;   // rows per wave
+constexpr int X_STATS = 8;  // partial sums per workgroup (seven used)
+
+__global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict__ gray, int H, int W, int gpitch, int grows,
+                                                       int high, unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long red[4][X_STATS];
+    const int frame = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const uint8_t* gp = gray + (int64_t)frame * grows * gpitch + (int64_t)GRAY_YOFF * gpitch + GRAY_XOFF;
+    unsigned long long v[X_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (x < W) {
+        const int xl = x > 0 ? x - 1 : 0, xr = x + 1 < W ? x + 1 : W - 1;
+#pragma unroll
+        for (int i = 0; i < X_ROWS; ++i) {
+            const int y = (blockIdx.y * 4 + wv) * X_ROWS + i;
+            if (y < H) {
+                const uint8_t* r1 = gp + (int64_t)y * gpitch;
+                const uint8_t* r0 = gp + (int64_t)(y > 0 ? y - 1 : 0) * gpitch;
+                const uint8_t* r2 = gp + (int64_t)(y + 1 < H ? y + 1 : H - 1) * gpitch;
+                const int a = r0[xl], b = r0[x], c = r0[xr];
+                const int d = r1[xl], e = r1[x], f = r1[xr];
+                const int g = r2[xl], h = r2[x], k = r2[xr];
+                const int gx = (c + 2 * f + k) - (a + 2 * d + g);
+                const int gy = (g + 2 * h + k) - (a + 2 * b + c);
+                const int mag = abs(gx) + abs(gy);
+                v[0] += (unsigned long long)mag;
+                v[1] += (unsigned long long)(mag * mag);
+                v[2] += mag > high ? 1u : 0u;
+                if (x > 0) v[(x & 7) == 0 ? 3 : 4] += (unsigned long long)abs(e - d);
+                if (y > 0) v[(y & 7) == 0 ? 5 : 6] += (unsigned long long)abs(e - b);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[s] += __shfl_xor(v[s], o, 64);
+        if (lane == 0) red[wv][s] = v[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int64_t blk = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[blk * X_STATS + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void extended_reduce_kernel(const unsigned long long* __restrict__ part, int blocks,
+                                                              FrameAcc* __restrict__ acc) {
+    __shared__ unsigned long long red[7][4];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = tid; b < blocks; b += 256) {
+        const unsigned long long* p = part + ((int64_t)frame * blocks + b) * X_STATS;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if ((tid & 63) == 0) red[k][tid >> 6] = v[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t[7];
+        for (int k = 0; k < 7; ++k) t[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+        acc[frame].sobel_sum = t[0];
+        acc[frame].sobel_sumsq = t[1];
+        acc[frame].sobel_strong = (uint32_t)t[2];
+        acc[frame].blk[0] = t[3];
+        acc[frame].blk[1] = t[4];
+        acc[frame].blk[2] = t[5];
+        acc[frame].blk[3] = t[6];
+    }
+}
+
+static dim3 extended_grid(const Geom& g, int n_frames) {
+    return dim3((g.W + 63) / 64, (g.H + 4 * X_ROWS - 1) / (4 * X_ROWS), n_frames);
+}
+size_t extended_part_bytes(const Geom& g, int n_frames) {
+    const dim3 grid = extended_grid(g, n_frames);
+    return (size_t)grid.x * grid.y * grid.z * X_STATS * sizeof(unsigned long long);
+}
+
+void launch_extended(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int high, unsigned long long* part,
+                     FrameAcc* acc) {
+    const dim3 grid = extended_grid(g, n_frames);
+    hipLaunchKernelGGL(extended_kernel, grid, dim3(256), 0, s, gray, g.H, g.W, g.gpitch, g.grows, high, part);
+    hipLaunchKernelGGL(extended_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, (int)(grid.x * grid.y), acc);
+}
+
+}  // namespace stx

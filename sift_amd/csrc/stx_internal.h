@@ -23,6 +23,13 @@ struct FrameAcc {
     long long lap_sum;
     unsigned long long lap_sumsq;
     unsigned long long gray_sumsq;
+    // extended statistics (only filled by the extended entry points)
+    uint32_t lbp_hist2[STX_LBP_MAX_BINS];  // second and third LBP radius
+    uint32_t lbp_hist3[STX_LBP_MAX_BINS];
+    unsigned long long sobel_sum, sobel_sumsq;
+    unsigned long long blk[4];  // |differences| across 8-pixel boundaries / inside blocks, horizontal then vertical
+    uint32_t sobel_strong;
+    uint32_t pad1;
 };
 
 // Geometry of one chunk of equally sized frames in the workspace.
@@ -70,7 +77,11 @@ void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom
 // Returns false when the radius needs a halo that does not fit an LDS tile.
 size_t lbp_generic_part_bytes(const Geom& g, int n_frames);
 bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
-                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out);
+                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out, int hist_slot = 0);
+// Sobel-magnitude and 8x8 blockiness sums per frame into acc[] (stx_extended.hip).
+size_t extended_part_bytes(const Geom& g, int n_frames);
+void launch_extended(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int high, unsigned long long* part,
+                     FrameAcc* acc);
 
 // One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
 // changed nothing.  changed[] must be zeroed before pass 0.  tile_count: [frame][bm_tiles][bm_words].

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
 
 // Per-frame sum of the tile histograms, in a fixed order.
 __global__ __launch_bounds__(256) void lbp_hist_reduce_kernel(const uint32_t* __restrict__ part, int tiles, int bins,
-                                                              FrameAcc* __restrict__ acc) {
+                                                              FrameAcc* __restrict__ acc, int hist_slot) {
     __shared__ uint32_t red[8][GL_BINS];
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int q = tid & (GL_BINS - 1), grp = tid >> 5;
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void lbp_hist_reduce_kernel(const uint32_t* __
     if (tid < bins) {
         uint32_t v = 0;
         for (int g = 0; g < 8; ++g) v += red[g][tid];
-        acc[frame].lbp_hist[tid] = v;
+        uint32_t* h = hist_slot == 0 ? acc[frame].lbp_hist : (hist_slot == 1 ? acc[frame].lbp_hist2 : acc[frame].lbp_hist3);
+        h[tid] = v;
     }
 }
 
@@ -141,7 +142,7 @@ size_t lbp_generic_part_bytes(const Geom& g, int n_frames) {
 }
 
 bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
-                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out) {
+                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out, int hist_slot) {
     LbpGenArgs a;
     a.gray = gray; a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.P = P;
     a.off = off; a.part = part; a.codes = codes_out;
@@ -190,7 +191,7 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
     for (int p = 0; p < P; ++p) a.lim[p] = (dr1[p] == 0 && dc1[p] == 0) ? 0u : 2u * a.margin;
     dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
     hipLaunchKernelGGL(lbp_generic_kernel, grid, dim3(256), lds, s, a);
-    hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, lbp_generic_tiles(g), P + 2, acc);
+    hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, lbp_generic_tiles(g), P + 2, acc, hist_slot);
     return true;
 }
 

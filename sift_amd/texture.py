@@ -14,7 +14,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import StxError, StxMetrics, StxParams, StxTiming
+from ._lib import StxError, StxExtended, StxMetrics, StxParams, StxTiming
 
 METRIC_KEYS = ("lbp_variance", "noise_level", "compression_artifacts", "edge_density", "frequency_anomaly")
 
@@ -130,6 +130,28 @@ class TextureContext:
 
     def max_async_frames(self, h: int, w: int) -> int:
         return int(self.lib.stx_max_async_frames(self.handle, h, w))
+
+    # ---- extended statistics
+    def analyze_frames_extended(self, frames: Sequence[np.ndarray], params: Optional[StxParams] = None):
+        """analyze_frames plus one StxExtended record per frame: (metrics array, extended array)."""
+        n = len(frames)
+        out = (StxMetrics * max(n, 1))()
+        ext = (StxExtended * max(n, 1))()
+        if n == 0:
+            return out, ext
+        keep, ptrs, h, w, stride = self._frame_ptrs(frames)
+        rc = self.lib.stx_analyze_extended_frames(self.handle, ptrs, n, h, w, stride,
+                                                  C.byref(params) if params is not None else None, out, ext)
+        self._check(rc, "stx_analyze_extended_frames")
+        return out, ext
+
+    def analyze_device_extended(self, dev_ptr: int, n: int, h: int, w: int, params: Optional[StxParams] = None):
+        out = (StxMetrics * max(n, 1))()
+        ext = (StxExtended * max(n, 1))()
+        rc = self.lib.stx_analyze_extended_batch_device(self.handle, dev_ptr, n, h, w, 3 * w, 3 * w * h,
+                                                        C.byref(params) if params is not None else None, out, ext)
+        self._check(rc, "stx_analyze_extended_batch_device")
+        return out, ext
 
     # ---- frame preparation of the CNN branch
     def preprocess_frames(self, frames: Sequence[np.ndarray], out_h: int = 80, out_w: int = 80) -> np.ndarray:
