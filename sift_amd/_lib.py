@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsift_texture.so")
+# SIFT_TEXTURE_LIB selects another build of the library (A/B timing of kernels)
+LIB_PATH = os.environ.get("SIFT_TEXTURE_LIB") or os.path.join(_HERE, "libsift_texture.so")
 
 STX_OK = 0
 LBP_MAX_BINS = 26

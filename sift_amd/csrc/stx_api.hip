@@ -74,7 +74,9 @@ struct stx_ctx {
     hipStream_t stream_fft = nullptr;  // FFT rows + columns
     std::string err;
     Slot slot[N_SLOTS];
-    DevBuf codes, plane, taps, prep_out;
+    DevBuf codes, plane, taps, prep_out, tie;
+    int tie_ncls = 0;
+    double tie_key[4] = {0, 0, 0, 0};  // the offsets the tie tables were built for
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
     bool concurrent_fft = true;
@@ -396,10 +398,21 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
     HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
+    if (lbp81) {
+        const double key[4] = {pr.off.rp[1], pr.off.rp[5], pr.off.cp[1], pr.off.cp[3]};
+        if (!c->tie.p || memcmp(key, c->tie_key, sizeof(key)) != 0) {
+            std::vector<uint8_t> blob;
+            build_tie_tables(pr.off, &blob, &c->tie_ncls);
+            if ((rc = ensure(c, c->tie, blob.size())) != STX_OK) return rc;
+            HIPCHK(c, hipMemcpy(c->tie.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            memcpy(c->tie_key, key, sizeof(key));
+        }
+    }
     {
         Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
         launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
-                       (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr);
+                       (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr,
+                       (const uint8_t*)c->tie.p, c->tie_ncls);
         sp.end();
     }
     if (!lbp81) {
@@ -620,6 +633,7 @@ int stx_destroy(stx_ctx* c) {
     if (c->codes.p) (void)hipFree(c->codes.p);
     if (c->plane.p) (void)hipFree(c->plane.p);
     if (c->taps.p) (void)hipFree(c->taps.p);
+    if (c->tie.p) (void)hipFree(c->tie.p);
     if (c->prep_out.p) (void)hipFree(c->prep_out.p);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);

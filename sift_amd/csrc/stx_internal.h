@@ -2,6 +2,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 #include "../../include/sift_texture.h"
@@ -71,7 +73,11 @@ void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t 
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out);
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, int n_cls_c);
+// Tables the (P=8,R=1) LBP uses for flat neighbourhoods (built on the host once per context and copied to the
+// device as one blob); TIE_COORDS entries per coordinate table cover every row / column a tile can touch.
+constexpr int TIE_COORDS = STX_MAX_DIM + 256;
+void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_cls_c);
 
 // Any (P <= 24, R): per-tile histograms into part (lbp_generic_part_bytes), then summed into acc[].lbp_hist.
 // Returns false when the radius needs a halo that does not fit an LDS tile.

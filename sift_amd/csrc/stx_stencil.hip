@@ -22,6 +22,9 @@
 // wave-wide queue in LDS and are re-evaluated in the order-exact fp64 sequence by whichever lane is
 // free, so the slow path costs ceil(queued / 64) rounds per block of rows instead of the worst lane's
 // count.  This file must be compiled with -ffp-contract=off.
+#include <utility>
+#include <vector>
+
 #include "stx_internal.h"
 
 namespace stx {
@@ -114,7 +117,7 @@ __device__ __forceinline__ void wave_sync() {
 
 // One bilinear sample exactly as skimage's bilinear_interpolation: top/bottom rows first,
 // then the vertical blend; returns the LBP bit (sample - centre >= 0).
-__device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, double bl, double br, double dr, double dc,
+__host__ __device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, double bl, double br, double dr, double dc,
                                             double centre) {
     const double omc = 1.0 - dc;
     const double omr = 1.0 - dr;
@@ -136,7 +139,17 @@ struct StencilArgs {
     uint32_t* strong;  // [frame][bm_words][W] 64-bit words, written as 32-bit halves (one per 32-row strip)
     uint32_t* cand;
     uint8_t* codes;    // optional per-pixel LBP codes [frame][H][W]
+    // Outcome of the four diagonal samples when a pixel and its eight neighbours are all equal: the fp64
+    // blend of four equal values is not always that value, and what it rounds to depends only on the value
+    // and on the fractional sample offsets, which take a handful of distinct values over all coordinates.
+    // One blob (one pointer: kernel arguments live in scalar registers for the whole kernel):
+    //   [0, TIE_COORDS)              row y    -> class of the row's two fractional offsets
+    //   [TIE_COORDS, 2*TIE_COORDS)   column x -> class of the column's two fractional offsets
+    //   [2*TIE_COORDS]               number of column classes
+    //   [TIE_LUT_OFF ...)            [row class][column class][gray level] -> nibble in the layout of sgd_lo/sgd_hi
+    const uint8_t* tie;
 };
+constexpr int TIE_LUT_OFF = 2 * TIE_COORDS + 256;
 
 // byte selectors for v_perm_b32 over {hi source, lo source}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = zero
 constexpr uint32_t SEL_PAIR = 0x0c010c00;   // (b0, b1) of the low source
@@ -426,6 +439,55 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         }
                         wave_sync();
                     }
+                    else if (!BORDER) {
+                        // Flat regions first, all rows of the block at once: where the four columns x-1 .. x+2
+                        // hold one value over three consecutive rows, both pixels of the middle row have a flat
+                        // neighbourhood and their nibbles come from the table instead of sixteen trips through
+                        // the fp64 sequence.  Rolled loops: this runs for flat content only and must not cost
+                        // the common path registers.
+                        const uint8_t* tp = tile + (yb - 1 - y0 + 2) * LPITCH + (x - x0 + GRAY_XOFF) - 1;
+                        uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0, elig = 0;
+                        uint32_t cv_lo = 0, cv_hi = 0;  // centre values of rows 0..3 / 4..7, one byte each
+#pragma unroll 1
+                        for (int r = 0; r < BLOCK_ROWS + 2; ++r) {
+                            const uint32_t b0 = tp[r * LPITCH], b1 = tp[r * LPITCH + 1], b2 = tp[r * LPITCH + 2],
+                                           b3 = tp[r * LPITCH + 3];
+                            const uint32_t f = (((b0 ^ b1) | (b1 ^ b2) | (b2 ^ b3)) == 0) ? 1u : 0u;
+                            if (r >= 2 && (f & f1 & f0) != 0 && b0 == v1 && v1 == v0) elig |= 1u << (r - 2);
+                            if (r >= 1 && r <= 4) cv_lo |= b1 << (8 * (r - 1));
+                            if (r >= 5 && r <= 8) cv_hi |= b1 << (8 * (r - 5));
+                            f0 = f1; v0 = v1; f1 = f; v1 = b0;
+                        }
+                        uint32_t want = 0;
+#pragma unroll
+                        for (int i = 0; i < BLOCK_ROWS; ++i) want |= ((elig >> i) & 1u) * (3u << (2 * (BLOCK_ROWS - 1 - i)));
+                        want &= pend;
+                        if (want != 0) {
+                            const uint8_t* tie = a.tie;
+                            const uint32_t cc = *reinterpret_cast<const uint16_t*>(tie + TIE_COORDS + x);
+                            const unsigned long long crp = *reinterpret_cast<const unsigned long long*>(tie + yb);
+                            const uint32_t ncc = tie[2 * TIE_COORDS];
+                            const uint8_t* tie_lut = tie + TIE_LUT_OFF;
+#pragma unroll 1
+                            for (int i = 0; i < BLOCK_ROWS; i += 2) {
+                                uint32_t l[4];
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const uint32_t base = ((uint32_t)(crp >> (8 * (i + k))) & 0xFFu) * ncc;
+                                    const uint32_t cv = (((i + k) < 4 ? cv_lo : cv_hi) >> (8 * ((i + k) & 3))) & 0xFFu;
+                                    l[2 * k] = tie_lut[((base + (cc & 0xFFu)) << 8) + cv];
+                                    l[2 * k + 1] = tie_lut[((base + (cc >> 8)) << 8) + cv];
+                                }
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const int sh = 4 * (BLOCK_ROWS - 1 - (i + k));
+                                    if ((want >> (2 * (BLOCK_ROWS - 1 - (i + k)) + 1)) & 1u) sgd_lo = (sgd_lo & ~(0xFu << sh)) | (l[2 * k] << sh);
+                                    if ((want >> (2 * (BLOCK_ROWS - 1 - (i + k)))) & 1u) sgd_hi = (sgd_hi & ~(0xFu << sh)) | (l[2 * k + 1] << sh);
+                                }
+                            }
+                            pend &= ~want;
+                        }
+                    }
                     for (uint32_t qb = 0;; qb += 64) {
                         bool active;
                         uint32_t item = 0;
@@ -576,7 +638,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (tid < 64) red[tid >> 4][tid & 15] = 0;
     __syncthreads();
 
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the per-wave LDS bases in scalar registers
     const int ys = y0 + wv * WAVE_ROWS;
     if (ys < a.H) {
         // interior: the wave's strip and its two-pixel halo lie inside the image
@@ -619,10 +682,44 @@ static uint32_t weight_pair(double wr, double dc, double* epos, double* eneg) {
 }
 static double frac(double v) { return v - floor(v); }
 
+// Tables for flat neighbourhoods, in the layout StencilArgs::tie describes.
+void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_cls_c) {
+    const double rp_neg = off.rp[1], rp_pos = off.rp[5], cp_pos = off.cp[1], cp_neg = off.cp[3];
+    std::vector<std::pair<double, double>> rcls, ccls;
+    blob->assign((size_t)TIE_LUT_OFF, 0);
+    auto classify = [&](std::vector<std::pair<double, double>>& cls, double oa, double ob, uint8_t* dst) {
+        for (int v = 0; v < TIE_COORDS; ++v) {
+            const double fa = (double)v + oa, fb = (double)v + ob;
+            const std::pair<double, double> d(fa - floor(fa), fb - floor(fb));
+            size_t k = 0;
+            while (k < cls.size() && cls[k] != d) ++k;
+            if (k == cls.size()) cls.push_back(d);
+            dst[v] = (uint8_t)k;
+        }
+    };
+    classify(rcls, rp_neg, rp_pos, blob->data());
+    classify(ccls, cp_pos, cp_neg, blob->data() + TIE_COORDS);
+    *n_cls_c = (int)ccls.size();
+    (*blob)[2 * (size_t)TIE_COORDS] = (uint8_t)ccls.size();
+    blob->resize((size_t)TIE_LUT_OFF + rcls.size() * ccls.size() * 256);
+    uint8_t* lut = blob->data() + TIE_LUT_OFF;
+    for (size_t r = 0; r < rcls.size(); ++r)
+        for (size_t k = 0; k < ccls.size(); ++k)
+            for (int v = 0; v < 256; ++v) {
+                const double drN = rcls[r].first, drP = rcls[r].second, dcP = ccls[k].first, dcN = ccls[k].second;
+                const double d = (double)v;
+                const uint32_t b1 = lbp_bit(d, d, d, d, drN, dcP, d), b3 = lbp_bit(d, d, d, d, drN, dcN, d);
+                const uint32_t b5 = lbp_bit(d, d, d, d, drP, dcN, d), b7 = lbp_bit(d, d, d, d, drP, dcP, d);
+                lut[(r * ccls.size() + k) * 256 + v] = (uint8_t)((((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu));
+            }
+}
+
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out) {
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, int n_cls_c) {
     StencilArgs a;
+    a.tie = tie_blob;
+    (void)n_cls_c;
     a.gray = gray;
     a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.bm_words = g.bm_words;
     // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound

@@ -35,3 +35,9 @@ SCORE_SETS = [
     ("natural_12frames", "natural", 12, 48, 80), ("empty", "noise", 0, 64, 64),
     ("natural_odd", "natural", 4, 45, 77),
 ]
+
+# Flat patches of hashed gray levels at large coordinates: (h, w, cell).  Every patch interior is an exact tie
+# of all four diagonal (8,1) samples, whose fp64 outcome depends on the gray level and on how row + offset and
+# column + offset round at that coordinate (the rounding changes at 512, 1024, 2048, 4096).  Goldens keep the
+# histogram and a digest of the code image.
+PATCHWORK_CASES = [(1100, 2100, 12), (300, 8192, 40), (8192, 150, 9), (130, 260, 64)]

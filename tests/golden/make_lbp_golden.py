@@ -18,7 +18,10 @@ sys.path.insert(0, HERE)
 import skimage  # noqa: E402
 from skimage.feature import local_binary_pattern  # noqa: E402
 
-from cases import LBP_IMAGES, LBP_PR, SEED  # noqa: E402
+import hashlib  # noqa: E402
+
+from cases import LBP_IMAGES, LBP_PR, PATCHWORK_CASES, SEED  # noqa: E402
+from patchwork import patchwork_gray  # noqa: E402
 from sift_amd.synth import synth_frame  # noqa: E402
 from lattice import lattice_image  # noqa: E402
 
@@ -37,5 +40,9 @@ for idx, (kind, h, w) in enumerate(LBP_IMAGES):
 lat = lattice_image()
 for (P, R) in LBP_PR:
     out["lbp_lattice_P%d" % P] = local_binary_pattern(lat, P=P, R=R, method="uniform").astype(np.uint8)
+for (h, w, cell) in PATCHWORK_CASES:
+    codes = local_binary_pattern(patchwork_gray(h, w, cell), P=8, R=1.0, method="uniform").astype(np.uint8)
+    out["patch_%dx%d_c%d_hist" % (h, w, cell)] = np.bincount(codes.ravel(), minlength=10).astype(np.int64)
+    out["patch_%dx%d_c%d_sha256" % (h, w, cell)] = np.array(hashlib.sha256(codes.tobytes()).hexdigest())
 np.savez_compressed(os.path.join(HERE, "lbp_skimage.npz"), **out)
 print("wrote", len(out), "arrays; skimage", skimage.__version__)

@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from cases import SEED
+from cases import PATCHWORK_CASES, SEED
+from patchwork import patchwork_gray
 from oracle import texture_oracle as O
 from sift_amd.synth import KIND_ID, synth_clip, synth_frame
 
@@ -49,6 +50,23 @@ def test_full_frame_vs_oracle(ctx, coracle, kind, h, w):
     assert np.array_equal(gray, g)
     assert np.array_equal(codes, coracle.lbp(g)[0])
     assert np.array_equal(edges, coracle.canny(g)[0])
+
+
+@pytest.mark.parametrize("h,w,cell", PATCHWORK_CASES)
+def test_flat_patches_vs_skimage_golden(ctx, h, w, cell):
+    """Flat patches: every interior pixel is an exact tie of the four diagonal samples, resolved from the
+    table for flat neighbourhoods.  Checked against scikit-image's own codes (histogram and digest)."""
+    import hashlib
+    import os
+    g = patchwork_gray(h, w, cell)
+    f = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))  # B = G = R: the gray plane is g itself
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbp_skimage.npz"))
+    key = "patch_%dx%d_c%d" % (h, w, cell)
+    r = ctx.analyze_frames([f])[0]
+    assert np.array_equal(np.array(r.lbp_hist[:10], dtype=np.int64), gold[key + "_hist"])
+    gray, codes, edges = ctx.debug_planes(f)
+    assert np.array_equal(gray, g)
+    assert hashlib.sha256(codes.tobytes()).hexdigest() == str(gold[key + "_sha256"])
 
 
 def test_1080p_clip_properties(ctx, coracle):
