@@ -48,7 +48,7 @@ GROUPS = {"texture": ("gray", "stencil", "lbp_generic"), "hysteresis": ("hystere
 
 def measured_traffic(h: int, w: int):
     """Per-frame HBM bytes per kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r1_c_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_d_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
