@@ -164,7 +164,7 @@ struct RowD {
 };
 
 template <bool BORDER, bool DO_LBP, bool CODES>
-__device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const unsigned long long* lut,
+__device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const uint2* lut,
                                       uint16_t* wq /*[QUEUE_ITEMS] per wave*/, uint32_t* wsg /*[128] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
@@ -280,7 +280,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         mag_row(ys, rw[1].d, rw[2].d, rw[3].d, rw[1].sm, rw[3].sm, mg[1]);
     }
 
-    unsigned long long hist_lo = 0, hist_hi = 0;  // ten 6-bit counters per pixel column (at most 32 rows each)
+    // Ten 6-bit counters for both pixel columns together: bins 0..4 in one word, 5..9 in the other, so that a
+    // row's two table entries are added with one three-operand add per word.  A counter holds at most 63 and
+    // 16 rows add at most 32: the first half of the strip is set aside after two blocks.
+    uint32_t hist_a = 0, hist_b = 0, hist_a0 = 0, hist_b0 = 0;
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
     uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, newest row lowest, per half
     uint32_t accS0 = 0, accC0 = 0;    // rows 0..15 of the strip
@@ -330,6 +333,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     sgA[i] = bfi(0x80008000u, r0, bfi(0x40004000u, r2 >> 1, bfi(0x20002000u, r4 >> 2, r6 >> 3)));
                     // diagonal samples in 16.16 fixed point, offset by the margin: t = (sample - centre) + margin.
                     // t < 0 or t > 2*margin settles the sign (and then sign(t) is the sign); otherwise queue.
+                    const uint32_t lim1 = 2 * a.margin + 1;  // t <= 2*margin  <=>  t - lim1 < 0
                     const uint32_t init_lo = a.margin - (c2 << 16);
                     const uint32_t init_hi = a.margin - (c2 & 0xFFFF0000u);
                     uint32_t tmin;
@@ -339,9 +343,11 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t t5 = dot2(rw[2].zm1, a.w5t, dot2(rw[3].zm1, a.w5b, init_lo));  // (+.7,-.7)
                         const uint32_t t7 = dot2(rw[2].z0, a.w7t, dot2(rw[3].z0, a.w7b, init_lo));    // (+.7,+.7)
                         sgd_lo = push_sign(push_sign(push_sign(push_sign(sgd_lo, t1), t3), t5), t7);
-                        tmin = min(min(t1, t3), min(t5, t7));
-                        if (BORDER) tmin = (vmy & 0xFFFFu) ? tmin : 0xFFFFFFFFu;
-                        pend = (pend << 1) | (tmin <= 2 * a.margin ? 1u : 0u);
+                        // samples below the centre wrap to huge values: the unsigned minimum is the smallest
+                        // t >= 0 (capped at 2^31 - 1 so that the subtraction's sign bit is the flag)
+                        tmin = min(min(min(t1, t3), t5), min(t7, 0x7FFFFFFFu));
+                        if (BORDER) tmin = (vmy & 0xFFFFu) ? tmin : 0x7FFFFFFFu;
+                        pend = push_sign(pend, tmin - lim1);
                     }
                     {
                         const uint32_t t1 = dot2(rw[1].zp1, a.w1t, dot2(rw[2].zp1, a.w1b, init_hi));
@@ -349,9 +355,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t t5 = dot2(rw[2].z0, a.w5t, dot2(rw[3].z0, a.w5b, init_hi));
                         const uint32_t t7 = dot2(rw[2].zp1, a.w7t, dot2(rw[3].zp1, a.w7b, init_hi));
                         sgd_hi = push_sign(push_sign(push_sign(push_sign(sgd_hi, t1), t3), t5), t7);
-                        tmin = min(min(t1, t3), min(t5, t7));
-                        if (BORDER) tmin = (vmy >> 16) ? tmin : 0xFFFFFFFFu;
-                        pend = (pend << 1) | (tmin <= 2 * a.margin ? 1u : 0u);
+                        tmin = min(min(min(t1, t3), t5), min(t7, 0x7FFFFFFFu));
+                        if (BORDER) tmin = (vmy >> 16) ? tmin : 0x7FFFFFFFu;
+                        pend = push_sign(pend, tmin - lim1);
                     }
                 }
                 // ---- Canny non-maximum suppression + double threshold on both pixels at once.  The sign
@@ -525,7 +531,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         wave_sync();  // the next block's queue must not overtake these reads
                     }
                 }
-                // ---- codes and histogram of this block: the eight sign bits index a table of 1 << 6*code
+                // ---- codes and histogram of this block: the eight sign bits index a table of one-hot 6-bit counters
 #pragma unroll
                 for (int i = 0; i < BLOCK_ROWS; ++i) {
                     const int y = yb + i;
@@ -536,12 +542,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         il = (y < H && x < W) ? il : (uint32_t)LUT_INVALID;
                         ih = (y < H && x + 1 < W) ? ih : (uint32_t)LUT_INVALID;
                     }
-                    const unsigned long long el = lut[il], eh = lut[ih];
-                    hist_lo += el;
-                    hist_hi += eh;
+                    const uint2 el = lut[il], eh = lut[ih];
+                    hist_a += el.x + eh.x;
+                    hist_b += el.y + eh.y;
                     if (CODES) {
-                        if (el) a.codes[((int64_t)frame * H + y) * W + x] = (uint8_t)((__ffsll(el) - 1) / 6);
-                        if (eh) a.codes[((int64_t)frame * H + y) * W + x + 1] = (uint8_t)((__ffsll(eh) - 1) / 6);
+                        auto code_of = [](uint2 e) -> uint8_t { return (uint8_t)(e.x ? (__ffs(e.x) - 1) / 6 : 5 + (__ffs(e.y) - 1) / 6); };
+                        if (el.x | el.y) a.codes[((int64_t)frame * H + y) * W + x] = code_of(el);
+                        if (eh.x | eh.y) a.codes[((int64_t)frame * H + y) * W + x + 1] = code_of(eh);
                     }
                 }
             }
@@ -549,6 +556,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         if (blk == 1) {
             accS0 = accS; accC0 = accC;
             accS = 0; accC = 0;
+            hist_a0 = hist_a; hist_b0 = hist_b;
+            hist_a = 0; hist_b = 0;
         }
     }
 
@@ -571,7 +580,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // ---- wave reduction: 10 histogram bins as 16-bit fields (a strip holds 4096 pixels), four sums
     unsigned long long w0 = 0, w1 = 0, w2 = 0;
     {
-        auto bin = [&](int b) -> unsigned long long { return ((hist_lo >> (6 * b)) & 63ull) + ((hist_hi >> (6 * b)) & 63ull); };
+        auto bin = [&](int b) -> unsigned long long {
+            const int sh = 6 * (b % 5);
+            return b < 5 ? ((hist_a >> sh) & 63u) + ((hist_a0 >> sh) & 63u) : ((hist_b >> sh) & 63u) + ((hist_b0 >> sh) & 63u);
+        };
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             w0 |= bin(b) << (16 * b);
@@ -603,7 +615,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 template <bool DO_LBP, bool CODES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stencil_kernel(StencilArgs a) {
     __shared__ uint32_t tile[LROWS * LDW];
-    __shared__ unsigned long long lut[LUT_INVALID + 2];
+    __shared__ uint2 lut[LUT_INVALID + 2];
     __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
     __shared__ uint32_t wsg[4][128];
     __shared__ uint32_t red[4][16];
@@ -632,8 +644,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const int changes = __popc((pat ^ (pat >> 1)) & 0x7Fu);
         const int code = (changes <= 2) ? __popc(pat) : 9;
-        lut[tid] = 1ull << (6 * code);
-        if (tid < 2) lut[LUT_INVALID + tid] = 0;
+        lut[tid] = code < 5 ? make_uint2(1u << (6 * code), 0u) : make_uint2(0u, 1u << (6 * (code - 5)));
+        if (tid < 2) lut[LUT_INVALID + tid] = make_uint2(0u, 0u);
     }
     if (tid < 64) red[tid >> 4][tid & 15] = 0;
     __syncthreads();
