@@ -9,15 +9,17 @@
 //               count(mag > canny_high)
 //   dh(y,x)   = |g(y,x) - g(y,x-1)|, x >= 1: "boundary" when x % 8 == 0, else "interior"
 //   dv(y,x)   = |g(y,x) - g(y-1,x)|, y >= 1: likewise with y
-// A wave covers 64 columns of a row, i.e. eight 8-pixel blocks: the boundary lanes are lane % 8 == 0,
-// and the per-wave sums come from one cross-lane reduction per statistic at the end.
+// A wave covers 64 columns, i.e. eight 8-pixel blocks: the boundary lanes are lane % 8 == 0, and the
+// per-wave sums come from one cross-lane reduction per statistic at the end.
 #include "stx_internal.h"
 
 namespace stx {
 
-constexpr int X_ROWS = 4;   // rows per wave
+constexpr int X_ROWS = 16;  // rows per wave
 constexpr int X_STATS = 8;  // partial sums per workgroup (seven used)
 
+// A lane walks down one column: the three pixels (x-1, x, x+1) of the rows above and below stay in
+// registers, so a pixel costs three byte loads; the sums of a lane's 16 rows fit 32 bits.
 __global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict__ gray, int H, int W, int gpitch, int grows,
                                                        int high, unsigned long long* __restrict__ part) {
     __shared__ unsigned long long red[4][X_STATS];
@@ -25,35 +27,42 @@ __global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
     const uint8_t* gp = gray + (int64_t)frame * grows * gpitch + (int64_t)GRAY_YOFF * gpitch + GRAY_XOFF;
-    unsigned long long v[X_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (x < W) {
+    uint32_t v[X_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int y0 = (blockIdx.y * 4 + wv) * X_ROWS;
+    if (x < W && y0 < H) {
         const int xl = x > 0 ? x - 1 : 0, xr = x + 1 < W ? x + 1 : W - 1;
+        const bool xedge = (x & 7) == 0;
+        auto row = [&](int y, int& l, int& m, int& r) {
+            const uint8_t* p = gp + (int64_t)(y < 0 ? 0 : (y < H ? y : H - 1)) * gpitch;
+            l = p[xl]; m = p[x]; r = p[xr];
+        };
+        int a, b, c, d, e, f, g, h, k;
+        row(y0 - 1, a, b, c);
+        row(y0, d, e, f);
 #pragma unroll
         for (int i = 0; i < X_ROWS; ++i) {
-            const int y = (blockIdx.y * 4 + wv) * X_ROWS + i;
+            const int y = y0 + i;
+            row(y + 1, g, h, k);
             if (y < H) {
-                const uint8_t* r1 = gp + (int64_t)y * gpitch;
-                const uint8_t* r0 = gp + (int64_t)(y > 0 ? y - 1 : 0) * gpitch;
-                const uint8_t* r2 = gp + (int64_t)(y + 1 < H ? y + 1 : H - 1) * gpitch;
-                const int a = r0[xl], b = r0[x], c = r0[xr];
-                const int d = r1[xl], e = r1[x], f = r1[xr];
-                const int g = r2[xl], h = r2[x], k = r2[xr];
                 const int gx = (c + 2 * f + k) - (a + 2 * d + g);
                 const int gy = (g + 2 * h + k) - (a + 2 * b + c);
                 const int mag = abs(gx) + abs(gy);
-                v[0] += (unsigned long long)mag;
-                v[1] += (unsigned long long)(mag * mag);
+                v[0] += (uint32_t)mag;
+                v[1] += (uint32_t)(mag * mag);
                 v[2] += mag > high ? 1u : 0u;
-                if (x > 0) v[(x & 7) == 0 ? 3 : 4] += (unsigned long long)abs(e - d);
-                if (y > 0) v[(y & 7) == 0 ? 5 : 6] += (unsigned long long)abs(e - b);
+                if (x > 0) v[xedge ? 3 : 4] += (uint32_t)abs(e - d);
+                if (y > 0) v[(y & 7) == 0 ? 5 : 6] += (uint32_t)abs(e - b);
             }
+            a = d; b = e; c = f;
+            d = g; e = h; f = k;
         }
     }
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
+        unsigned long long t = v[s];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[s] += __shfl_xor(v[s], o, 64);
-        if (lane == 0) red[wv][s] = v[s];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) red[wv][s] = t;
     }
     __syncthreads();
     if (threadIdx.x < 7) {

@@ -7,8 +7,8 @@
 // A 256-thread workgroup owns a 64x64 pixel tile held in LDS with a zero-filled halo (pixels
 // outside the image are 0.0 for scikit-image).  Every sample is a bilinear blend of a 2x2
 // cell whose position relative to the centre and whose four weights are the same for every
-// pixel, so they are tabulated once per launch: the blend runs in 16.16 fixed point (four
-// 24-bit multiply-adds) and decides the sign whenever the result is further from the centre
+// pixel, so they are tabulated once per launch: the blend runs in 16.16 fixed point (two
+// v_dot2_u32_u16 over packed pixel pairs) and decides the sign whenever the result is further from the centre
 // than the rounding of the weights can explain; the remaining samples (ties, mostly) are
 // replayed in scikit-image's fp64 operation order, one rounding per operation: compile with
 // -ffp-contract=off.  Histograms leave the kernel as one partial per tile (no global atomics).
@@ -21,25 +21,39 @@ namespace stx {
 constexpr int GL_TILE = 64;        // tile width and height
 constexpr int GL_ROWS = GL_TILE / 4;  // rows per wave
 constexpr int GL_BINS = 32;        // partial histogram slots per tile (P + 2 <= 26 used)
+constexpr int GL_COPIES = 16;      // copies of the workgroup's histogram in LDS
+constexpr int GL_HSTRIDE = 33;     // words between copies
 
 struct LbpGenArgs {
     const uint8_t* gray;
     int H, W, gpitch, grows, P;
-    int halo, lpitch;     // zero-filled border of the LDS tile, bytes per tile row
+    int halo, lpitch;     // zero-filled border of the LDS tile, entries per tile row
     uint32_t margin;      // bound on |fixed-point sample - exact sample| in 1/65536 gray levels, plus a guard
-    int ofs[24];          // LDS byte offset of the cell's top-left pixel relative to the centre pixel
-    int dcol[24];         // 0 or 1: the cell's right column
-    int drow[24];         // 0 or lpitch: the cell's lower row
-    uint32_t w[24][4];    // 16.16 weights of top-left, top-right, bottom-left, bottom-right
-    uint32_t lim[24];     // 2*margin, or 0 for samples that sit exactly on a pixel (always decided)
+    int otop[24];         // LDS byte offset of the cell's top-left pixel relative to the centre pixel
+    int obot[24];         // ... of its bottom-left pixel (same as otop for a cell of one row)
+    uint32_t wtop[24];    // 16.16 weights (left | right << 16) of the upper cell row
+    uint32_t wbot[24];    // ... of the lower cell row (zero for a cell of one row)
+    uint32_t lim[24];     // 2*margin + 1, or 0 for samples that sit exactly on a pixel (always decided)
     LbpOffsets off;       // the exact sample offsets for the fp64 path
     uint32_t* part;       // [frame][tiles][GL_BINS]
     uint8_t* codes;       // optional per-pixel codes
 };
 
+// The LDS tile holds, for every pixel position, the pixel and its right neighbour as one packed pair
+// (low half = the pixel, high half = the next one): a cell row is then one aligned 32-bit read and one
+// v_dot2_u32_u16 with the row's two weights.  PT > 0 unrolls the sample loop for that P (the per-sample
+// constants become scalar registers loaded in batches); PT == 0 is the loop for any other P.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t b, uint32_t acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), acc, false);
+}
+
+template <int PT>
 __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
-    extern __shared__ uint8_t gl_tile[];  // (GL_TILE + 2*halo) rows of lpitch bytes
-    __shared__ uint32_t hist[GL_BINS];
+    extern __shared__ uint32_t gl_tile[];  // (GL_TILE + 2*halo) rows of lpitch pairs
+    // Sixteen copies of the histogram, 33 words apart (a copy per bank offset): neighbouring pixels mostly
+    // fall into the same bin, and 64 lanes adding to one LDS word would be served one after the other.
+    __shared__ uint32_t hist[GL_COPIES * GL_HSTRIDE];
     __shared__ double offs[2][24];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
@@ -51,35 +65,46 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     for (int i = tid; i < trows * lpitch; i += 256) {
         const int r = i / lpitch, cidx = i - r * lpitch;
         const int gy = y0 - halo + r, gx = x0 - halo + cidx;
-        uint8_t v = 0;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = gp[(int64_t)(gy + GRAY_YOFF) * a.gpitch + gx + GRAY_XOFF];
+        uint32_t v = 0;
+        if (gy >= 0 && gy < a.H) {
+            const uint8_t* rowp = gp + (int64_t)(gy + GRAY_YOFF) * a.gpitch + GRAY_XOFF;
+            if (gx >= 0 && gx < a.W) v = rowp[gx];
+            if (gx + 1 >= 0 && gx + 1 < a.W) v |= (uint32_t)rowp[gx + 1] << 16;
+        }
         gl_tile[i] = v;
     }
-    if (tid < GL_BINS) hist[tid] = 0;
+    for (int i = tid; i < GL_COPIES * GL_HSTRIDE; i += 256) hist[i] = 0;
     if (tid < 24) { offs[0][tid] = a.off.rp[tid]; offs[1][tid] = a.off.cp[tid]; }
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
     const int x = x0 + lane;
-    const int P = a.P;
+    const int P = PT > 0 ? PT : a.P;
     const uint32_t pmask = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u);
     if (x < a.W) {
         for (int i = 0; i < GL_ROWS; ++i) {
             const int y = y0 + wv * GL_ROWS + i;
             if (y >= a.H) break;
             const int pa = (halo + wv * GL_ROWS + i) * lpitch + halo + lane;
-            const uint32_t c = gl_tile[pa];
+            const uint8_t* pb = reinterpret_cast<const uint8_t*>(gl_tile) + 4 * pa;
+            const uint32_t c = gl_tile[pa] & 0xFFFFu;
             const uint32_t init = a.margin - (c << 16);
             uint32_t signs = 0, near = 0;  // sample p at bit P-1-p
-            for (int p = 0; p < P; ++p) {
-                const int a00 = pa + a.ofs[p];
-                const int a10 = a00 + a.drow[p];
-                const uint32_t v00 = gl_tile[a00], v01 = gl_tile[a00 + a.dcol[p]];
-                const uint32_t v10 = gl_tile[a10], v11 = gl_tile[a10 + a.dcol[p]];
+            auto sample = [&](int p) {
                 // t = (sample - centre) + margin in 1/65536 gray levels
-                const uint32_t t = v00 * a.w[p][0] + v01 * a.w[p][1] + v10 * a.w[p][2] + v11 * a.w[p][3] + init;
-                signs = (signs << 1) | (t >> 31);
-                near = (near << 1) | (t <= a.lim[p] ? 1u : 0u);
+                const uint32_t top = *reinterpret_cast<const uint32_t*>(pb + a.otop[p]);
+                const uint32_t bot = *reinterpret_cast<const uint32_t*>(pb + a.obot[p]);
+                const uint32_t t = dot2(top, a.wtop[p], dot2(bot, a.wbot[p], init));
+                signs = __builtin_amdgcn_alignbit(signs, t, 31);
+                // 0 <= t <= 2*margin: too close to call (t < lim as unsigned; lim = 0 never flags).  Written as an
+                // add so that the comparison's carry feeds the doubling of near directly.
+                near = near + near + (t < a.lim[p] ? 1u : 0u);
+            };
+            if (PT > 0) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) sample(p);
+            } else {
+                for (int p = 0; p < P; ++p) sample(p);
             }
             uint32_t bits = ~signs & pmask;  // LBP bit = sample >= centre
             while (near != 0) {
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
                 const int maxr = (int)ceil(rf), maxc = (int)ceil(cf);
                 const double dr = rf - fr, dc = cf - fc;
                 auto px = [&](int yy, int xx) -> double {
-                    return (double)gl_tile[(yy - y0 + halo) * lpitch + (xx - x0 + halo)];
+                    return (double)(gl_tile[(yy - y0 + halo) * lpitch + (xx - x0 + halo)] & 0xFFFFu);
                 };
                 const double tl = px(minr, minc), tr = px(minr, maxc), bl = px(maxr, minc), br = px(maxr, maxc);
                 const double top = (1.0 - dc) * tl + dc * tr;
@@ -107,14 +132,17 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
             const uint32_t pairmask = (P >= 2) ? ((1u << (P - 1)) - 1u) : 0u;
             const int changes = __popc((bits ^ (bits >> 1)) & pairmask);
             const int code = (changes <= 2) ? __popc(bits) : P + 1;
-            atomicAdd(&hist[code], 1u);
+            atomicAdd(&hist[(lane & (GL_COPIES - 1)) * GL_HSTRIDE + code], 1u);
             if (a.codes) a.codes[((int64_t)frame * a.H + y) * a.W + x] = (uint8_t)code;
         }
     }
     __syncthreads();
     if (tid < GL_BINS) {
         const int64_t tileid = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.part[tileid * GL_BINS + tid] = hist[tid];
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < GL_COPIES; ++k) v += hist[k * GL_HSTRIDE + tid];
+        a.part[tileid * GL_BINS + tid] = v;
     }
 }
 
@@ -164,33 +192,52 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
         if (need_r > halo) halo = need_r;
         if (need_c > halo) halo = need_c;
     }
-    const int lpitch = ((GL_TILE + 2 * halo + 3) / 4) * 4;
-    const size_t lds = (size_t)(GL_TILE + 2 * halo) * lpitch;
+    // odd pitch in 32-bit entries: consecutive tile rows start in different LDS banks
+    const int lpitch = (GL_TILE + 2 * halo) | 1;
+    const size_t lds = (size_t)(GL_TILE + 2 * halo) * lpitch * sizeof(uint32_t);
     if (lds > 60 * 1024) return false;  // radius beyond what one tile with its halo can hold
     a.halo = halo; a.lpitch = lpitch;
-    for (int p = 0; p < 24; ++p) {
-        a.ofs[p] = 0; a.dcol[p] = 0; a.drow[p] = 0; a.lim[p] = 0;
-        for (int k = 0; k < 4; ++k) a.w[p][k] = 0;
-    }
+    for (int p = 0; p < 24; ++p) { a.otop[p] = 0; a.obot[p] = 0; a.wtop[p] = 0; a.wbot[p] = 0; a.lim[p] = 0; }
     for (int p = 0; p < P; ++p) {
-        a.ofs[p] = fr[p] * lpitch + fc[p];
-        a.dcol[p] = dc1[p];
-        a.drow[p] = dr1[p] * lpitch;
+        a.otop[p] = 4 * (fr[p] * lpitch + fc[p]);
+        a.obot[p] = a.otop[p] + 4 * dr1[p] * lpitch;
         const double wex[4] = {(1.0 - wr[p]) * (1.0 - wc[p]), (1.0 - wr[p]) * wc[p], wr[p] * (1.0 - wc[p]), wr[p] * wc[p]};
         double ep = 0.0, en = 0.0;
+        uint32_t q4[4];
         for (int k = 0; k < 4; ++k) {
             const double exact = 65536.0 * wex[k];
             const long long q = llround(exact);
             const double e = (double)q - exact;
             if (e > 0) ep += e; else en -= e;
-            a.w[p][k] = (uint32_t)q;
+            q4[k] = (uint32_t)q;
+        }
+        // a weight of exactly 65536 (a sample on a pixel) does not fit 16 bits: split it between the two
+        // rows of the "cell", which are the same row then
+        if (dr1[p] == 0 && dc1[p] == 0) {
+            a.wtop[p] = 32768u; a.wbot[p] = 32768u;
+        } else if (dr1[p] == 0) {
+            // one row, two columns: the lower row's weights are zero; split the upper row over both reads
+            a.wtop[p] = (q4[0] >> 1) | ((q4[1] >> 1) << 16);
+            a.wbot[p] = (q4[0] - (q4[0] >> 1)) | ((q4[1] - (q4[1] >> 1)) << 16);
+        } else if (dc1[p] == 0) {
+            // one column, two rows
+            a.wtop[p] = q4[0] >= 65536u ? 65535u : q4[0];
+            a.wbot[p] = q4[2] >= 65536u ? 65535u : q4[2];
+        } else {
+            a.wtop[p] = q4[0] | (q4[1] << 16);
+            a.wbot[p] = q4[2] | (q4[3] << 16);
         }
         worst = fmax(worst, 255.0 * fmax(ep, en));
     }
     a.margin = (uint32_t)ceil(worst) + 2u;
-    for (int p = 0; p < P; ++p) a.lim[p] = (dr1[p] == 0 && dc1[p] == 0) ? 0u : 2u * a.margin;
+    for (int p = 0; p < P; ++p) a.lim[p] = (dr1[p] == 0 && dc1[p] == 0) ? 0u : 2u * a.margin + 1u;
     dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
-    hipLaunchKernelGGL(lbp_generic_kernel, grid, dim3(256), lds, s, a);
+    switch (P) {
+        case 8: hipLaunchKernelGGL(lbp_generic_kernel<8>, grid, dim3(256), lds, s, a); break;
+        case 16: hipLaunchKernelGGL(lbp_generic_kernel<16>, grid, dim3(256), lds, s, a); break;
+        case 24: hipLaunchKernelGGL(lbp_generic_kernel<24>, grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL(lbp_generic_kernel<0>, grid, dim3(256), lds, s, a); break;
+    }
     hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, lbp_generic_tiles(g), P + 2, acc, hist_slot);
     return true;
 }
