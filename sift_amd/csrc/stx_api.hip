@@ -412,7 +412,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
         launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
                        (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr,
-                       (const uint8_t*)c->tie.p, c->tie_ncls);
+                       (const uint8_t*)c->tie.p);
         sp.end();
     }
     if (!lbp81) {

@@ -728,10 +728,9 @@ void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, int n_cls_c) {
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob) {
     StencilArgs a;
     a.tie = tie_blob;
-    (void)n_cls_c;
     a.gray = gray;
     a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.bm_words = g.bm_words;
     // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound
