@@ -25,8 +25,9 @@ struct __attribute__((aligned(4))) Bgr4 {
 constexpr int GRAY_ROWS_PER_BLOCK = 4;
 
 // grid, wide frames: x = 256-dword column blocks of a padded row, y = groups of 4 padded rows, z = frame;
-// narrow frames (FLAT): x = 256-thread blocks over (row group, dword column) pairs numbered row group
-// major, so that crops fill their workgroups too.
+// narrow frames (FLAT): x = 256-thread blocks over (row group, dword column) pairs, so that crops fill their
+// workgroups too; the dword columns that lie fully inside the image are numbered first (row group major) and
+// the ones that touch the reflected border after them, so that a wave runs one of the two code paths.
 // A thread converts the same four-pixel column of four consecutive rows: four independent 12-byte
 // loads in flight per lane, and a quarter of the workgroups to dispatch.
 template <bool FLAT>
@@ -36,8 +37,24 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ b
     const int frame = blockIdx.z;
     const int dpr = gpitch >> 2;
     const int id = blockIdx.x * 256 + threadIdx.x;
-    const int rgroup = FLAT ? id / dpr : (int)blockIdx.y;
-    const int dc = FLAT ? id - rgroup * dpr : id;
+    int rgroup, dc;
+    if (FLAT) {
+        // dword columns 1 .. W/4 hold four image pixels each
+        const int nfast = W >> 2, nslow = dpr - nfast;
+        const int groups = (grows + GRAY_ROWS_PER_BLOCK - 1) / GRAY_ROWS_PER_BLOCK;
+        if (id < groups * nfast) {
+            rgroup = id / nfast;
+            dc = 1 + id - rgroup * nfast;
+        } else {
+            const int k = id - groups * nfast;
+            rgroup = k / nslow;
+            const int q = k - rgroup * nslow;
+            dc = q == 0 ? 0 : nfast + q;
+        }
+    } else {
+        rgroup = (int)blockIdx.y;
+        dc = id;
+    }
     if (dc >= dpr || rgroup * GRAY_ROWS_PER_BLOCK >= grows) return;
     const int x = 4 * dc - GRAY_XOFF;
     const uint8_t* fsrc = bgr + (int64_t)frame * frame_stride;
