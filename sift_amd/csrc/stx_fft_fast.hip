@@ -774,19 +774,26 @@ void launch_rows_t(hipStream_t s, RowsArgs a, int n_frames) {
     const int pairs = (a.fh + 1) / 2;
     a.groups = (pairs + P::TPW - 1) / P::TPW;
     a.total_units = n_frames * a.groups;
-    // as many single-wave workgroups as the LDS of 256 CUs holds at once (at most 16 per CU)
-    const int lds_bytes = P::TPW * P::S * (int)sizeof(float2);
-    int per_cu = (160 * 1024) / (lds_bytes + 256);
-    per_cu = per_cu > 16 ? 16 : (per_cu < 1 ? 1 : per_cu);
-    const int grid = a.total_units < 256 * per_cu ? a.total_units : 256 * per_cu;
+    // A persistent grid: exactly as many single-wave workgroups as the device holds at once (registers and LDS
+    // both limit that; a larger grid would run its surplus as a second, mostly empty round).
+    auto launch = [&](auto kernel) {
+        static int per_cu = 0;  // per instantiation
+        if (per_cu == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64, 0) != hipSuccess || n < 1) n = 8;
+            per_cu = n > 16 ? 16 : n;
+        }
+        const int grid = a.total_units < 256 * per_cu ? a.total_units : 256 * per_cu;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, a);
+    };
     if constexpr (Direct<P>::ok) {
         // narrow loads need B-byte aligned rows: gray rows start 4-byte aligned, the crop origin decides
         if ((a.fox & 3) == 0 && (a.gpitch & 3) == 0) {
-            hipLaunchKernelGGL((rows_kernel<P, true>), dim3(grid), dim3(64), 0, s, a);
+            launch(rows_kernel<P, true>);
             return;
         }
     }
-    hipLaunchKernelGGL((rows_kernel<P, false>), dim3(grid), dim3(64), 0, s, a);
+    launch(rows_kernel<P, false>);
 }
 
 template <class P>
