@@ -342,6 +342,20 @@ __device__ __forceinline__ void transform_to(float2* buf, const float2* twg, int
     else pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t, st);
 }
 
+// the passes after the first one (whose outputs are already in buf)
+template <class P, class Sink>
+__device__ __forceinline__ void transform_tail_to(float2* buf, const float2* twg, int t, Sink& last) {
+    constexpr int NP = (P::R3 > 1) ? 4 : (P::R2 > 1) ? 3 : (P::R1 > 1) ? 2 : 1;
+    static_assert(NP >= 2, "nothing after the first pass");
+    StoreSink<P::SWZ> st{buf};
+    if constexpr (NP == 2) pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, twg, t, st);
+    if constexpr (NP == 3) pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, twg, t, st);
+    if constexpr (NP == 4) pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t, last);
+    else pass<P::N, P::R3, P::R0 * P::R1 * P::R2, P::LPT, P::SWZ>(buf, twg, t, st);
+}
+
 template <class P>
 __device__ __forceinline__ void transform(float2* buf, const float2* twg, int t) {
     StoreSink<P::SWZ> st{buf};
@@ -671,6 +685,19 @@ struct ColsArgs {
     double2* part;  // [frame][nkb*cbw]
 };
 
+// First column pass straight from global memory.  Butterfly j of the radix-R0 first pass reads rows
+// j + r*M0 (M0 = N/R0) of one column.  A 16-byte load holds one row of two adjacent columns, so a thread
+// that loads rows j + r*M0, r = 0..R0-1, of one column pair has every input of two butterflies, and
+// consecutive threads (column pair fastest, then j) read consecutive 16-byte pieces: the block streams in
+// as before, but goes through the first butterflies on its way into LDS instead of being parked there
+// first -- one LDS write and one LDS read less per element.  With one column per wave the workgroup has
+// 64*cbw threads for M0*cbw/2 such tasks: one round when M0 <= 128.
+template <class P>
+struct ColsDirect {
+    static constexpr int M0 = P::N / P::R0;
+    static constexpr bool ok = P::TPW == 1 && P::R1 > 1 && P::R0 > 1 && P::R0 <= 10 && M0 <= 128;
+};
+
 // blockDim.x = 64 * cbw / TPW ; dynamic LDS = cbw * S float2
 template <class P>
 __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
@@ -681,7 +708,38 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     const int cbw = a.cbw;
     // the block [N][cbw] is contiguous in global memory
     const float2* src = a.spec + ((int64_t)frame * a.nkb + kb) * (int64_t)N * cbw;
-    if (cbw >= 2) {
+    bool first_pass_done = false;
+    if constexpr (ColsDirect<P>::ok) {
+        if (cbw >= 2) {
+            constexpr int R0 = P::R0, M0 = ColsDirect<P>::M0;
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            const int half = cbw >> 1;
+            const int cp = tid & (half - 1), j = tid >> (a.cbw_log2 - 1);
+            if (j < M0) {
+                float4 q[R0];
+#pragma unroll
+                for (int r = 0; r < R0; ++r) q[r] = src4[(j + r * M0) * half + cp];
+                float2 v0[R0], v1[R0];
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    v0[r] = make_float2(q[r].x, q[r].y);
+                    v1[r] = make_float2(q[r].z, q[r].w);
+                }
+                Dft<R0>::run(v0);
+                Dft<R0>::run(v1);
+                float2* b0 = dynlds + (2 * cp) * S;
+                float2* b1 = b0 + S;
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    b0[pad<P::SWZ>(j * R0 + r)] = v0[r];
+                    b1[pad<P::SWZ>(j * R0 + r)] = v1[r];
+                }
+            }
+            first_pass_done = true;
+        }
+    }
+    if (first_pass_done) {
+    } else if (cbw >= 2) {
         // N*cbw/2 16-byte loads over 64*cbw/TPW threads: N*TPW/128 per thread whatever cbw is.  All of a
         // thread's loads are issued before the first LDS write, so the block arrives at memory latency once,
         // not once per load.
@@ -729,7 +787,12 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     } sink;
     sink.dc_fix = 128.0f * (float)N * (float)a.fw;
     sink.dc_col = (k == 0);
-    transform_to<P>(buf, a.tw, t, sink);
+    if constexpr (ColsDirect<P>::ok) {
+        if (first_pass_done) transform_tail_to<P>(buf, a.tw, t, sink);
+        else transform_to<P>(buf, a.tw, t, sink);
+    } else {
+        transform_to<P>(buf, a.tw, t, sink);
+    }
     double ls = sink.ls, ls2 = sink.ls2;
     if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; }  // columns past the half spectrum hold no data
 #pragma unroll
