@@ -424,12 +424,16 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
                         return ((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu;
                     };
+                    // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
+                    // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
+                    // next row, then lane 31 into the upper half
                     uint32_t inc = cnt;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t up = __shfl_up(inc, o, 64);
-                        inc += (lane >= o) ? up : 0u;
-                    }
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);  // row_bcast:15
+                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     // flat regions queue (nearly) every pixel: the lanes are evenly loaded as they are, and each
                     // keeps its own pixels (no queue, no LDS atomics on a shared word)
