@@ -33,7 +33,8 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
 // that pass".  From pass 1 on a tile is revisited only if it or one of its eight neighbours
 // changed in the previous pass.  nlines = image width, nwords = words per line, ntiles =
 // 64-line tiles across the image.
-__device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
+// returns (wave-uniform) whether the tile changed; changed may be null
+__device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
                                           int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
                                           uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half);
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
     }
 }
 
-__device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
+__device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
                                           int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
                                           uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half) {
     const int tpf = ntiles * nwords;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
             fl_cur[tl * nwords + wx] = 0;
             tile_count[tbase + tl * nwords + wx] = 0;
         }
-        return;
+        return false;
     }
     if (lin) {
         S = sb[ln];
@@ -137,7 +138,7 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
             fl_cur[tl * nwords + wx] = 0;
             tile_count[tbase + tl * nwords + wx] = 0;
         }
-        return;
+        return false;
     }
     unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
     unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
@@ -168,9 +169,75 @@ __device__ __forceinline__ void hyst_tile(unsigned long long* __restrict__ stron
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (lane == 0) {
         // a flag, not a count: every writer stores the same value, so a plain store is enough
-        if (tile_changed) changed[pass] = 1u;
+        if (tile_changed && changed) changed[pass] = 1u;
         fl_cur[tl * nwords + wx] = tile_changed ? 1 : 0;
         tile_count[tbase + tl * nwords + wx] = cnt;
+    }
+    return tile_changed;
+}
+
+// The tail of the hysteresis: after a few grid-wide passes only a handful of tiles per frame are still
+// growing, and a pass costs its launch.  Here one workgroup per frame repeats the pass over its own frame
+// (frames do not interact) until nothing changes, with a barrier instead of a launch between rounds.  Counts
+// as pass number `pass`; rounds alternate the flag parity like passes do.  A frame that is still changing
+// after HYST_FINISH_ROUNDS rounds (an odd number, so that its flags end in this pass's parity) reports it in
+// changed[pass] and the host queues the kernel again; a frame that is done clears both parities.
+constexpr int HYST_FINISH_ROUNDS = 63;
+__global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* __restrict__ strong,
+                                                           const unsigned long long* __restrict__ cand, int nlines,
+                                                           int nwords, int ntiles, unsigned int* changed, int pass,
+                                                           uint32_t* __restrict__ tile_count, uint8_t* tflag,
+                                                           int64_t tflag_half) {
+    if (changed[pass - 1] == 0) return;
+    __shared__ int round_changed[2];
+    const int frame = blockIdx.x;
+    const int tpf = ntiles * nwords;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int64_t tbase = (int64_t)frame * tpf;
+    if (threadIdx.x < 2) round_changed[threadIdx.x] = 0;
+    __syncthreads();
+    bool done = false;
+    for (int round = 0; round < HYST_FINISH_ROUNDS; ++round) {
+        const int p = pass + round;
+        const uint8_t* fl_prev = tflag + (int64_t)((p - 1) & 1) * tflag_half + tbase;
+        uint8_t* fl_cur = tflag + (int64_t)(p & 1) * tflag_half + tbase;
+        bool any = false;
+        for (int base = wave * 64; base < tpf; base += nwaves * 64) {
+            const int rem = base + lane;
+            int f = 0;
+            if (rem < tpf) {
+                const int tl = rem / nwords, wx = rem - tl * nwords;
+#pragma unroll
+                for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int nl = tl + dl, nx = wx + dx;
+                        if (nl >= 0 && nl < ntiles && nx >= 0 && nx < nwords) f |= fl_prev[nl * nwords + nx];
+                    }
+                if (!f) fl_cur[rem] = 0;
+            }
+            unsigned long long todo = __ballot(f != 0);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                any |= hyst_tile(strong, cand, nlines, nwords, ntiles, (int)(tbase + base + l), nullptr, p, tile_count, tflag,
+                                 tflag_half);
+            }
+        }
+        if (any && lane == 0) round_changed[round & 1] = 1;
+        __syncthreads();  // also orders this round's bitmap and flag stores before the next round's loads
+        const bool again = round_changed[round & 1] != 0;
+        if (threadIdx.x == 0) round_changed[(round + 1) & 1] = 0;
+        __syncthreads();
+        if (!again) { done = true; break; }
+    }
+    if (done) {
+        for (int i = threadIdx.x; i < tpf; i += blockDim.x) {
+            tflag[tbase + i] = 0;
+            tflag[tflag_half + tbase + i] = 0;
+        }
+    } else if (threadIdx.x == 0) {
+        changed[pass] = 1u;
     }
 }
 
@@ -243,6 +310,13 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(hyst_pass_kernel, dim3(grid), dim3(64 * HYST_WAVES), 0, s, strong,
                        cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half);
+}
+
+void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
+                        const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
+    const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
+    hipLaunchKernelGGL(hyst_finish_kernel, dim3(n_frames), dim3(1024), 0, s, strong, cand, g.W, g.bm_words, g.bm_tiles,
+                       changed, pass, tile_count, tflag, half);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

@@ -93,6 +93,10 @@ void launch_extended(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
 // changed nothing.  changed[] must be zeroed before pass 0.  tile_count: [frame][bm_tiles][bm_words].
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
+// Pass number `pass` >= 1 as one workgroup per frame that repeats the pass until the frame is done (or a
+// round limit is reached: then changed[pass] is set and the caller queues it again).
+void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
                          const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);

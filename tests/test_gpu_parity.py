@@ -225,6 +225,30 @@ def test_long_contours_hysteresis(ctx, coracle):
     assert ctx.analyze_frames([bgr])[0].edge_count == cnt
 
 
+def test_one_long_snake_needs_thousands_of_rounds(ctx, coracle):
+    # a single weak path that crosses the frame back and forth, hanging off one strong seed: the edge grows by
+    # one tile per pass, far beyond the grid passes queued with a chunk and beyond one continuation launch;
+    # the other frames of the batch finish at once
+    h, w = 520, 700
+    g = np.full((h, w), 40, np.uint8)
+    ys = list(range(8, h - 8, 10))
+    for k, y in enumerate(ys):
+        g[y:y + 3, 8:w - 8] = 60  # a faint band: both of its sides are weak edges
+        if k + 1 < len(ys):  # connect to the next band at alternating ends
+            x = w - 11 if k % 2 == 0 else 8
+            g[y:ys[k + 1] + 3, x:x + 3] = 60
+    g[6:12, 8:14] = 255  # the seed, on the first band
+    snake = np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))
+    frames = [snake, synth_frame("noise", SEED, 5, 0, h, w), synth_frame("flat", SEED, 5, 1, h, w)]
+    res = ctx.analyze_frames(frames)
+    for f, r in zip(frames, res):
+        assert r.edge_count == coracle.canny(coracle.gray(f))[2]
+    _, _, edges = ctx.debug_planes(snake)
+    assert np.array_equal(edges, coracle.canny(g)[0])
+    # the path really is connected end to end: its last line is an edge
+    assert edges[ys[-1] - 2:ys[-1] + 5, w // 2].any()
+
+
 def test_errors_are_python_exceptions(ctx, det):
     from sift_amd._lib import StxError
     with pytest.raises(ValueError):
