@@ -1,0 +1,29 @@
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
+import numpy as np
+from oracle import texture_oracle as O
+from sift_amd.texture import TextureContext
+from sift_amd.synth import synth_frame, KINDS
+ctx = TextureContext(0)
+c = O.COracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+for it in range(N):
+    h = int(rng.integers(1, 400)); w = int(rng.integers(1, 500))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    n = int(rng.integers(1, 4))
+    frames = [synth_frame(kind, 0x5EED0000 + it, it, i, h, w) for i in range(n)]
+    if rng.random() < 0.3:  # posterize: flat patches
+        q = int(rng.integers(2, 6))
+        frames = [np.ascontiguousarray((f >> q) << q) for f in frames]
+    res = ctx.analyze_frames(frames)
+    for f, r in zip(frames, res):
+        m = c.analyze_frame(f)
+        a = (tuple(r.lbp_hist[:10]), r.edge_count, r.absdiff_sum, r.hp_sum, r.hp_sumsq, r.gray_sum)
+        b = (tuple(m.lbp_hist[:10]), m.edge_count, m.absdiff_sum, m.hp_sum, m.hp_sumsq, m.gray_sum)
+        fa = abs(r.frequency_anomaly - m.frequency_anomaly) <= 1e-4 * max(abs(m.frequency_anomaly), 1e-9) + 1e-9
+        if a != b or not fa:
+            bad += 1
+            print("MISMATCH", it, kind, h, w, a, b, r.frequency_anomaly, m.frequency_anomaly, flush=True)
+print("fuzz done", N, "cases, mismatches:", bad)

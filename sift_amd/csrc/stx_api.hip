@@ -476,7 +476,8 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         }
         {
             Span sp(c, &sl.spans, STX_K_FFT_COLS, 1, sf);
-            launch_fft_cols(sf, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h, (double2*)sl.part.p);
+            launch_fft_cols(sf, (const uint8_t*)sl.gray.p, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h,
+                            (double2*)sl.part.p);
             sp.end();
         }
         if (sf != s) {

@@ -9,8 +9,10 @@
 //   cols:  a block of adjacent spectrum columns is transformed along H and reduced on the
 //          spot to sum / sum-of-squares of ln(|F|+1); the mirrored half of the spectrum is
 //          accounted for by weighting interior columns twice.  Nothing is written back.
-// The input is gray-128 to keep the DC term out of the fp32 dynamic range; only bin (0,0)
-// differs, by exactly 128*H*W, which the column kernel adds back.
+// The input is gray - m, m = the frame's gray level at the origin of the transformed region: it keeps
+// the DC term out of the fp32 dynamic range, and only bin (0,0) differs, by exactly m*H*W, which the
+// column kernel adds back.  Taking m from the frame (rather than a fixed 128) makes a constant frame
+// transform to exact zeros, as it does in the reference's fp64.
 #include "stx_internal.h"
 
 namespace stx {
@@ -136,13 +138,14 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(FftRowsArgs a) {
     const int frame = blockIdx.y;
     const int row0 = blockIdx.x * 2 * nb;
     const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
+    const int m = gp[(int64_t)(a.foy + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF];
     for (int b = 0; b < nb; ++b) {
         const int ra = row0 + 2 * b, rb = ra + 1;
         const uint8_t* pa = gp + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
         const uint8_t* pb = pa + a.gpitch;
         for (int x = tid; x < n; x += 256) {
-            const float va = ra < a.fh ? (float)((int)pa[x] - 128) : 0.f;
-            const float vb = rb < a.fh ? (float)((int)pb[x] - 128) : 0.f;
+            const float va = ra < a.fh ? (float)((int)pa[x] - m) : 0.f;
+            const float vb = rb < a.fh ? (float)((int)pb[x] - m) : 0.f;
             buf0[b * n + x] = make_float2(va, vb);
         }
     }
@@ -171,6 +174,8 @@ struct FftColsArgs {
     FftPlan plan;
     const float2* tw;
     double2* part;
+    const uint8_t* gray0;  // gray level at the origin of frame 0's transformed region; frames gstride apart
+    int64_t gstride;
 };
 
 __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     __syncthreads();
     const float2* f = fft_run(buf0, buf1, a.plan, cb, a.tw, tid, 256);
     double s = 0.0, s2 = 0.0;
-    const float dc_fix = 128.0f * (float)a.fh * (float)a.fw;
+    const float dc_fix = (float)a.gray0[(int64_t)frame * a.gstride] * (float)a.fh * (float)a.fw;
     for (int c = 0; c < cb; ++c) {
         const int k = k0 + c;
         if (k >= a.fwh) break;
@@ -295,14 +300,17 @@ void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
     hipLaunchKernelGGL(fft_rows_kernel, grid, dim3(256), lds, s, a);
 }
 
-void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
-                     const FftPlan& plan, const float2* tw, double2* part) {
-    if (lay.fast_cols && launch_fft_cols_fast(s, spec, n_frames, g, lay, tw, part)) return;
+void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int n_frames, const Geom& g,
+                     const FftLayout& lay, const FftPlan& plan, const float2* tw, double2* part) {
+    const uint8_t* gray0 = gray + (int64_t)(g.foy + GRAY_YOFF) * g.gpitch + g.fox + GRAY_XOFF;
+    const int64_t gstride = (int64_t)g.grows * g.gpitch;
+    if (lay.fast_cols && launch_fft_cols_fast(s, gray0, gstride, spec, n_frames, g, lay, tw, part)) return;
     FftColsArgs a;
     a.spec = spec; a.fh = g.fh; a.fw = g.fw; a.fwh = g.fwh;
     a.cb = lay.cbw;
     a.nblocks = lay.nkb;
     a.plan = plan; a.tw = tw; a.part = part;
+    a.gray0 = gray0; a.gstride = gstride;
     const int lds = 2 * a.cb * g.fh * (int)sizeof(float2);
     dim3 grid(a.nblocks, n_frames);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(256), lds, s, a);

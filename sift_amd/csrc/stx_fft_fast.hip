@@ -385,7 +385,7 @@ __device__ __forceinline__ uint32_t load_bytes(const uint8_t* p, int idx) {
 // ra / rb: the loads of the two image rows packed into one complex signal (row a real, row b imaginary)
 template <class P>
 __device__ __forceinline__ void pass0_direct(float2* __restrict__ buf, const uint32_t (&ra)[P::R0],
-                                             const uint32_t (&rb)[P::R0], int t) {
+                                             const uint32_t (&rb)[P::R0], float m, int t) {
     constexpr int R = P::R0, B = Direct<P>::B;
     float2 out[B * R];
 #pragma unroll
@@ -393,7 +393,7 @@ __device__ __forceinline__ void pass0_direct(float2* __restrict__ buf, const uin
         float2 v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            v[r] = make_float2((float)((ra[r] >> (8 * e)) & 255u) - 128.0f, (float)((rb[r] >> (8 * e)) & 255u) - 128.0f);
+            v[r] = make_float2((float)((ra[r] >> (8 * e)) & 255u) - m, (float)((rb[r] >> (8 * e)) & 255u) - m);
         Dft<R>::run(v);
 #pragma unroll
         for (int r = 0; r < R; ++r) out[e * R + r] = v[r];
@@ -532,6 +532,10 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     const bool aligned = DIRECT || (a.fox & 3) == 0;
 
     uint32_t ra_reg[NL], rb_reg[NL];
+    // The transform runs on gray - m, m = the frame's gray level at the origin of the transformed region (only
+    // bin (0,0) depends on m; the column pass adds m*H*W back): a constant frame becomes exact zeros.  m travels
+    // with the prefetched rows; rows that do not exist are set to m when the unit is consumed.
+    uint32_t m_reg = 0;
     auto row_ptr = [&](int unit, int& frame, int& ra) -> const uint8_t* {
         frame = unit / a.groups;
         const int grp = unit - frame * a.groups;
@@ -539,10 +543,14 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         return a.gray + (int64_t)frame * a.grows * a.gpitch + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox +
                GRAY_XOFF;
     };
+    auto origin = [&](int frame) -> const uint8_t* {
+        return a.gray + (int64_t)frame * a.grows * a.gpitch + (int64_t)(a.foy + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
+    };
     auto fetch = [&](int unit) {
         int frame, ra;
         const uint8_t* pa = row_ptr(unit, frame, ra);
         const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
+        m_reg = origin(frame)[0];
         if constexpr (DIRECT) {
             constexpr int B = Direct<P>::B;
             if (ina && inb) {  // wave-uniform; every unit but the last row pair of an odd-height frame
@@ -554,8 +562,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
-                    ra_reg[i] = ina ? load_bytes<B>(pa, lane + 64 * i) : 0x80808080u;
-                    rb_reg[i] = 0x80808080u;
+                    ra_reg[i] = ina ? load_bytes<B>(pa, lane + 64 * i) : 0u;
+                    rb_reg[i] = 0u;
                 }
             }
         } else {
@@ -563,8 +571,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
             for (int i = 0; i < NL; ++i) {
                 const int x4 = lane + 64 * i;
                 const bool inx = (NL * 64 == N / 4) || x4 < N / 4;
-                ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
-                rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0x80808080u;
+                ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0u;
+                rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0u;
             }
         }
     };
@@ -584,6 +592,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         if constexpr (DIRECT || PREFETCH) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(ra_reg[i]), "+v"(rb_reg[i]));
+            asm volatile("" : "+v"(m_reg));
         }
     };
 
@@ -595,8 +604,21 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         const uint8_t* pa = row_ptr(unit, frame, ra);
         const uint8_t* pb = pa + a.gpitch;
         const bool ina = ra < a.fh, inb = ra + 1 < a.fh;
+        uint32_t mcur = m_reg;
+        if (!(DIRECT || (PREFETCH && aligned))) mcur = origin(frame)[0];
+        const float m = (float)mcur;
+        if constexpr (DIRECT || PREFETCH) {
+            if (!ina || !inb) {  // wave-uniform and rare: rows past the end of the frame transform as zeros
+                const uint32_t m4 = mcur * 0x01010101u;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    if (!ina) ra_reg[i] = m4;
+                    if (!inb) rb_reg[i] = m4;
+                }
+            }
+        }
         if constexpr (DIRECT) {
-            pass0_direct<P>(buf, ra_reg, rb_reg, t);
+            pass0_direct<P>(buf, ra_reg, rb_reg, m, t);
             if (unit + (int)gridDim.x < a.total_units) fetch(unit + gridDim.x);
         } else if (PREFETCH && aligned) {
 #pragma unroll
@@ -607,8 +629,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                     float2 e[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        e[q] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
-                                           (float)((int)((wb >> (8 * q)) & 255u) - 128));
+                        e[q] = make_float2((float)((wa >> (8 * q)) & 255u) - m, (float)((wb >> (8 * q)) & 255u) - m);
                     if constexpr (!P::SWZ) {
                         // 16-byte stores: half the bank conflicts of four strided 8-byte stores
                         float4* d4 = reinterpret_cast<float4*>(buf + 4 * x4);
@@ -623,17 +644,17 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
             if (unit + (int)gridDim.x < a.total_units) fetch(unit + gridDim.x);
         } else if ((N % 4 == 0) && aligned) {
             for (int x4 = t; x4 < N / 4; x4 += LPT) {
-                const uint32_t wa = ina ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0x80808080u;
-                const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : 0x80808080u;
+                const uint32_t fill = mcur * 0x01010101u;
+                const uint32_t wa = ina ? reinterpret_cast<const uint32_t*>(pa)[x4] : fill;
+                const uint32_t wb = inb ? reinterpret_cast<const uint32_t*>(pb)[x4] : fill;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    buf[pad<P::SWZ>(4 * x4 + q)] = make_float2((float)((int)((wa >> (8 * q)) & 255u) - 128),
-                                                               (float)((int)((wb >> (8 * q)) & 255u) - 128));
+                    buf[pad<P::SWZ>(4 * x4 + q)] = make_float2((float)((wa >> (8 * q)) & 255u) - m, (float)((wb >> (8 * q)) & 255u) - m);
             }
         } else {
             for (int x = t; x < N; x += LPT)
                 buf[pad<P::SWZ>(x)] =
-                    make_float2(ina ? (float)((int)pa[x] - 128) : 0.f, inb ? (float)((int)pb[x] - 128) : 0.f);
+                    make_float2(ina ? (float)pa[x] - m : 0.f, inb ? (float)pb[x] - m : 0.f);
         }
         // One half-spectrum bin of both rows; column-blocked layout [kb][row][cbw].  The row part of the
         // address is wave-uniform (folded into the base pointer); the bin part depends on the lane only,
@@ -683,6 +704,8 @@ struct ColsArgs {
     int cbw_log2;
     const float2* tw;
     double2* part;  // [frame][nkb*cbw]
+    const uint8_t* gray0;  // gray level at the origin of frame 0's transformed region; frames gstride apart
+    int64_t gstride;
 };
 
 // First column pass straight from global memory.  Butterfly j of the radix-R0 first pass reads rows
@@ -785,8 +808,8 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
             ls2 += l * l;
         }
     } sink;
-    sink.dc_fix = 128.0f * (float)N * (float)a.fw;
     sink.dc_col = (k == 0);
+    sink.dc_fix = sink.dc_col ? (float)a.gray0[(int64_t)frame * a.gstride] * (float)N * (float)a.fw : 0.f;
     if constexpr (ColsDirect<P>::ok) {
         if (first_pass_done) transform_tail_to<P>(buf, a.tw, t, sink);
         else transform_to<P>(buf, a.tw, t, sink);
@@ -940,9 +963,10 @@ bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, cons
     }
 }
 
-bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
-                          const float2* tw, double2* part) {
+bool launch_fft_cols_fast(hipStream_t s, const uint8_t* gray0, int64_t gstride, const float2* spec, int n_frames,
+                          const Geom& g, const FftLayout& lay, const float2* tw, double2* part) {
     ColsArgs a;
+    a.gray0 = gray0; a.gstride = gstride;
     a.spec = spec; a.fw = g.fw; a.fwh = g.fwh; a.cbw = lay.cbw; a.nkb = lay.nkb; a.cbw_log2 = __builtin_ctz(lay.cbw);
     a.tw = tw; a.part = part;
     switch (g.fh) {

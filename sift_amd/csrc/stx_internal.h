@@ -112,8 +112,8 @@ struct FftLayout {
 FftLayout fft_choose_layout(const Geom& g);
 void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                      const FftPlan& plan, const float2* tw, float2* spec);
-void launch_fft_cols(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
-                     const FftPlan& plan, const float2* tw, double2* part);
+void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int n_frames, const Geom& g,
+                     const FftLayout& lay, const FftPlan& plan, const float2* tw, double2* part);
 // compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
 bool fft_fast_available(int n);
 int fft_fast_stride(int n);
@@ -121,8 +121,8 @@ int fft_fast_tpw(int n);
 hipError_t fft_fast_init();
 bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                           const float2* tw, float2* spec);
-bool launch_fft_cols_fast(hipStream_t s, const float2* spec, int n_frames, const Geom& g, const FftLayout& lay,
-                          const float2* tw, double2* part);
+bool launch_fft_cols_fast(hipStream_t s, const uint8_t* gray0, int64_t gstride, const float2* spec, int n_frames,
+                          const Geom& g, const FftLayout& lay, const float2* tw, double2* part);
 
 // Laplacian / gray-square sums per frame into acc[] (stx_quality.hip); part holds quality_part_bytes.
 size_t quality_part_bytes(const Geom& g, int n_frames);

@@ -71,10 +71,10 @@ def test_metrics_vs_oracle(ctx, coracle, kind):
         f = synth_frame(kind, SEED, 4, 2, h, w)
         r = ctx.analyze_frames([f])[0]
         m = coracle.analyze_frame(f)
-        # structured, noise-free images (ramp/flat/step) have most FFT bins at exactly zero in
+        # structured, noise-free images (ramp/step) have most FFT bins at exactly zero in
         # exact arithmetic; the fp32 noise floor shows in ln(|F|+1) there, so the spectral
         # statistic is only held to 2e-3 for them
-        rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+        rel = REL if kind in ("noise", "natural", "tie", "flat") else 2e-3
         _check_record(r, m, rel=rel)
 
 
@@ -132,7 +132,7 @@ def test_score_sets_golden(det):
         assert len(res["individual_scores"]) == min(n, 10)
         for a, b in zip(res["individual_scores"], want["individual_scores"]):
             assert a == pytest.approx(b, abs=1.001e-3)
-        rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+        rel = REL if kind in ("noise", "natural", "tie", "flat") else 2e-3
         for d, wd in zip(res["detailed_metrics"], want["detailed_metrics"]):
             assert list(d.keys()) == list(O.METRIC_KEYS)
             for k in O.METRIC_KEYS:
@@ -180,7 +180,7 @@ def test_device_resident_and_synth(ctx, coracle):
             assert np.array_equal(got, want), kind
             res = ctx.analyze_device(dev, n, h, w)
             for i in range(n):
-                rel = REL if kind in ("noise", "natural", "tie") else 2e-3
+                rel = REL if kind in ("noise", "natural", "tie", "flat") else 2e-3
                 _check_record(res[i], coracle.analyze_frame(want[i]), rel=rel)
     finally:
         ctx.device_free(dev)
@@ -247,6 +247,17 @@ def test_one_long_snake_needs_thousands_of_rounds(ctx, coracle):
     assert np.array_equal(edges, coracle.canny(g)[0])
     # the path really is connected end to end: its last line is an edge
     assert edges[ys[-1] - 2:ys[-1] + 5, w // 2].any()
+
+
+def test_constant_frames_spectrum_is_exact(det):
+    # the FFT runs on gray minus the frame's own first gray level: a constant frame transforms to exact zeros,
+    # as in the reference's fp64, and only bin (0,0) carries ln(v*H*W + 1)
+    for (h, w) in ((48, 64), (120, 160), (97, 131)):
+        for v in (0, 1, 77, 128, 255):
+            f = np.full((h, w, 3), v, np.uint8)
+            want = float(np.std(np.log(np.abs(np.fft.fft2(f[:, :, 0].astype(np.float64))) + 1)))
+            got = det.analyze_frame(f)["frequency_anomaly"]
+            assert got == pytest.approx(want, rel=1e-6, abs=1e-12), (h, w, v)
 
 
 def test_errors_are_python_exceptions(ctx, det):
