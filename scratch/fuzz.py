@@ -10,7 +10,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 for it in range(N):
-    h = int(rng.integers(1, 400)); w = int(rng.integers(1, 500))
+    big = rng.random() < 0.15
+    h = int(rng.integers(1, 1300 if big else 400)); w = int(rng.integers(1, 2200 if big else 500))
     kind = KINDS[int(rng.integers(0, len(KINDS)))]
     n = int(rng.integers(1, 4))
     frames = [synth_frame(kind, 0x5EED0000 + it, it, i, h, w) for i in range(n)]
