@@ -31,6 +31,30 @@ __device__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out
                          const float2* __restrict__ tw, int tid, int nthreads) {
     const int m = n / R;            // butterflies per transform
     const int twstep = n / (ns * R);
+    if (R != 2 && R != 3 && R != 4 && R != 5) {
+        // direct DFT of size R on the twiddled inputs (rare sizes only): one output per thread and step, so
+        // that a prime length (a single pass with one butterfly) still spreads over the workgroup
+        for (int b = 0; b < nb; ++b) {
+            const float2* ib = in + b * n;
+            float2* ob = out + b * n;
+            for (int idx = tid; idx < m * R; idx += nthreads) {
+                const int q = idx / m, j = idx - q * m;
+                const int k = j % ns;
+                const int o = (j - k) * R + k;
+                const int t1 = k * twstep;
+                float2 accv = make_float2(0.f, 0.f);
+                long e = 0;  // (r*t1 + r*q*m) mod n
+                const long step = ((long)t1 + (long)q * m) % n;
+                for (int r = 0; r < R; ++r) {
+                    accv = cadd(accv, cmul(ib[j + r * m], tw[e]));
+                    e += step;
+                    if (e >= n) e -= n;
+                }
+                ob[o + q * ns] = accv;
+            }
+        }
+        return;
+    }
     for (int b = 0; b < nb; ++b) {
         const float2* ib = in + b * n;
         float2* ob = out + b * n;
@@ -88,19 +112,6 @@ __device__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out
                 ob[o + 2 * ns] = cadd(p2, q2);
                 ob[o + 3 * ns] = csub(p2, q2);
                 ob[o + 4 * ns] = csub(p1, q1);
-            } else {
-                // direct DFT of size R on the twiddled inputs (rare sizes only)
-                for (int q = 0; q < R; ++q) {
-                    float2 accv = make_float2(0.f, 0.f);
-                    long e = 0;  // (r*t1 + r*q*m) mod n
-                    const long step = ((long)t1 + (long)q * m) % n;
-                    for (int r = 0; r < R; ++r) {
-                        accv = cadd(accv, cmul(ib[j + r * m], tw[e]));
-                        e += step;
-                        if (e >= n) e -= n;
-                    }
-                    ob[o + q * ns] = accv;
-                }
             }
         }
     }
