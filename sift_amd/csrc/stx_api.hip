@@ -426,11 +426,14 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
             memcpy(c->tie_key, key, sizeof(key));
         }
     }
+    // the second half of the tile flags doubles as "this tile holds a strong pixel" between the stencil and the first
+    // hysteresis pass (the second pass is the first to write it as change flags)
+    HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, s));
     {
         Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
         launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
                        (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr,
-                       (const uint8_t*)c->tie.p);
+                       (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words);
         sp.end();
     }
     if (!lbp81) {

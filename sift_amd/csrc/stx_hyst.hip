@@ -51,8 +51,39 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
     if (pass > 0 && changed[pass - 1] == 0) return;
     const int wave = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * HYST_WAVES;
     if (pass == 0) {
-        for (int tile_id = wave; tile_id < total_tiles; tile_id += nwaves)
-            hyst_tile(strong, cand, nlines, nwords, ntiles, tile_id, changed, pass, tile_count, tflag, tflag_half);
+        // The stencil left, in the flag half that pass 1 will overwrite, which tiles hold a strong pixel.  Nothing
+        // can grow in a tile with no strong pixel in it or in its eight neighbours: a wave tests 64 tiles at once
+        // (one per lane) and enters only the others.
+        const int lane0 = threadIdx.x & 63;
+        const int tpf0 = ntiles * nwords;
+        const uint8_t* sflag = tflag + tflag_half;
+        for (int j0 = 0; j0 * nwaves + wave < total_tiles; j0 += 64) {
+            const int tile_id = (j0 + lane0) * nwaves + wave;
+            int f = 0;
+            if (tile_id < total_tiles) {
+                const int frame = tile_id / tpf0;
+                const int rem = tile_id - frame * tpf0;
+                const int tl = rem / nwords, wx = rem - tl * nwords;
+                const uint8_t* sf = sflag + (int64_t)frame * tpf0;
+#pragma unroll
+                for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int nl = tl + dl, nx = wx + dx;
+                        if (nl >= 0 && nl < ntiles && nx >= 0 && nx < nwords) f |= sf[nl * nwords + nx];
+                    }
+                if (!f) {
+                    tflag[tile_id] = 0;
+                    tile_count[tile_id] = 0;
+                }
+            }
+            unsigned long long todo = __ballot(f != 0);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half);
+            }
+        }
         return;
     }
     // Later passes touch few tiles.  A wave looks at the flags of all its tiles at once, one tile per lane (the

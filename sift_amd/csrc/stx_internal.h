@@ -73,7 +73,7 @@ void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t 
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob);
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag);
 // Tables the (P=8,R=1) LBP uses for flat neighbourhoods (built on the host once per context and copied to the
 // device as one blob); TIE_COORDS entries per coordinate table cover every row / column a tile can touch.
 constexpr int TIE_COORDS = STX_MAX_DIM + 256;

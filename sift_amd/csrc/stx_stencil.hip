@@ -148,6 +148,10 @@ struct StencilArgs {
     //   [2*TIE_COORDS]               number of column classes
     //   [TIE_LUT_OFF ...)            [row class][column class][gray level] -> nibble in the layout of sgd_lo/sgd_hi
     const uint8_t* tie;
+    // [frame][ceil(W/64)][bm_words] bytes, zeroed by the caller: set to 1 for every 64x64 hysteresis tile that
+    // holds a strong pixel (the first hysteresis pass skips tiles with none in or around them unseen)
+    uint8_t* sflag;
+    int bm_tiles;
 };
 constexpr int TIE_LUT_OFF = 2 * TIE_COORDS + 256;
 
@@ -579,6 +583,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             a.strong[wi] = __brev((accS0 & 0xFFFF0000u) | (accS >> 16));
             a.cand[wi] = __brev((accC0 & 0xFFFF0000u) | (accC >> 16));
         }
+        // lanes 0..31 hold the columns of one hysteresis tile, lanes 32..63 those of the next
+        const unsigned long long sb = __ballot(x < W && (accS | accS0) != 0);
+        if (sb != 0 && lane == 0) {
+            uint8_t* f = a.sflag + ((int64_t)frame * a.bm_tiles + (x0 >> 6)) * a.bm_words + (ys >> 6);
+            if ((uint32_t)sb != 0) f[0] = 1;
+            if ((sb >> 32) != 0) f[a.bm_words] = 1;
+        }
     }
 
     // ---- wave reduction: 10 histogram bins as 16-bit fields (a strip holds 4096 pixels), four sums
@@ -732,8 +743,10 @@ void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_
 
 void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob) {
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag) {
     StencilArgs a;
+    a.sflag = sflag;
+    a.bm_tiles = g.bm_tiles;
     a.tie = tie_blob;
     a.gray = gray;
     a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.bm_words = g.bm_words;
