@@ -27,6 +27,7 @@ extern "C" {
 #define STX_ERR_NOMEM (-4)
 
 #define STX_LBP_MAX_BINS 26 /* P + 2 bins, P <= 24 */
+#define STX_FLAG_FFT_F64 1u /* stx_metrics.flags: fft_sum / fft_sumsq come from the fp64 transform */
 #define STX_MAX_DIM 8192    /* largest frame height or width */
 
 typedef struct stx_ctx stx_ctx;
@@ -38,10 +39,15 @@ typedef struct stx_params {
     double lbp_radius; /* R, default 1.0    (passive_checker.py:103) */
     int canny_low;     /* default 50        (passive_checker.py:116) */
     int canny_high;    /* default 150       (passive_checker.py:116) */
-    int gray_shift;    /* 14 (default) or 15: fixed-point width of the BGR->gray weights (:100) */
+    int gray_shift;    /* 15 (default: OpenCV 4.x's RGB2Gray<uchar>) or 14 (OpenCV 3.x): fixed-point width of the
+                          BGR->gray weights (:100) */
     int fft_h, fft_w;  /* 0,0 (default) = transform the whole frame (:120); else a centred crop */
     int quality_stats; /* 0 (default); 1 = also fill the frame-quality fields below, which the callers of the
                           texture path compute per frame (/root/reference/app/main.py:120-123, :209-216) */
+    int fft_exact;     /* precision of the transform behind frequency_anomaly (:120-123; numpy's is complex128):
+                          0 (default) = fp32, and any frame whose spectrum has enough near-zero bins for fp32 rounding
+                          noise to show in the statistic is transformed again in fp64; 1 = every frame in fp64;
+                          -1 = fp32 only */
 } stx_params;
 
 /* Per-frame result: the five metrics of passive_checker.py:125-131, the per-frame score
@@ -55,7 +61,7 @@ typedef struct stx_metrics {
     double texture_score;         /* weighted sum           :145-151 */
     uint32_t lbp_hist[STX_LBP_MAX_BINS]; /* histogram of uniform LBP codes 0..P+1 */
     uint32_t edge_count;          /* Canny edge pixels */
-    uint32_t reserved;
+    uint32_t flags;               /* STX_FLAG_* */
     uint64_t absdiff_sum;         /* sum |gray - GaussianBlur5x5(gray)| */
     uint64_t hp_sum;              /* sum of the saturated 3x3 high-pass image */
     uint64_t hp_sumsq;            /* sum of its squares */
@@ -72,11 +78,12 @@ typedef struct stx_metrics {
 
 /* Accumulated device time per kernel family, measured with HIP events on the stream
  * the kernels run on (only while stx_set_timing(ctx, 1) is in effect). */
-#define STX_N_KERNELS 8
+#define STX_N_KERNELS 10
 typedef struct stx_timing {
     double ms[STX_N_KERNELS];       /* total elapsed milliseconds */
     uint64_t launches[STX_N_KERNELS]; /* kernel launches counted into ms[] */
     uint64_t frames;                /* frames analysed while timing was on */
+    uint64_t fft64_frames;          /* frames since the last reset whose transform was repeated in fp64 (stx_params.fft_exact) */
 } stx_timing;
 /* indices into stx_timing.ms / .launches */
 #define STX_K_GRAY 0
@@ -86,7 +93,9 @@ typedef struct stx_timing {
 #define STX_K_FFT_ROWS 4
 #define STX_K_FFT_COLS 5
 #define STX_K_REDUCE 6
-#define STX_K_SYNTH 7 /* also counts the optional frame-quality pass */
+#define STX_K_SYNTH 7
+#define STX_K_QUALITY 8  /* the optional frame-quality pass (stx_params.quality_stats) */
+#define STX_K_EXTENDED 9 /* Sobel / blockiness sums of the extended entry points */
 
 const char* stx_version(void);
 

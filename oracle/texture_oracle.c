@@ -17,15 +17,17 @@ void orc_default_params(orc_params* p) {
     p->lbp_radius = 1.0;
     p->canny_low = 50;
     p->canny_high = 150;
-    p->gray_shift = 14;
+    p->gray_shift = 15;
     p->fft_h = 0;
     p->fft_w = 0;
 }
 
 /* ------------------------------------------------------------------ gray
  * cv2.cvtColor(frame, COLOR_BGR2GRAY) at passive_checker.py:100.  OpenCV's
- * 8-bit path is fixed point: 14-bit coefficients 1868/9617/4899 with
- * round-to-nearest (some builds use the 15-bit set 3735/19235/9798). */
+ * 8-bit path is fixed point with round-to-nearest.  OpenCV 4.x (what an
+ * unpinned `opencv-python-headless` installs, requirements.txt:5) uses the
+ * 15-bit coefficients 3735/19235/9798 in RGB2Gray<uchar>; OpenCV 3.x used the
+ * 14-bit set 1868/9617/4899 (shift == 14, kept as a knob). */
 void orc_bgr2gray(const uint8_t* bgr, int h, int w, int64_t row_stride, int shift, uint8_t* gray) {
     for (int y = 0; y < h; ++y) {
         const uint8_t* s = bgr + (int64_t)y * row_stride;

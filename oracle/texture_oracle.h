@@ -35,7 +35,7 @@ typedef struct {
     double lbp_radius; /* R; reference literal 1.0 (passive_checker.py:103) */
     int canny_low;     /* 50  (passive_checker.py:116) */
     int canny_high;    /* 150 (passive_checker.py:116) */
-    int gray_shift;    /* 14: (1868 B + 9617 G + 4899 R + 8192) >> 14; 15: 15-bit coefficients */
+    int gray_shift;    /* 15 (default): (3735 B + 19235 G + 9798 R + 16384) >> 15; 14: (1868 B + 9617 G + 4899 R + 8192) >> 14 */
     int fft_h, fft_w;  /* 0,0 = whole frame; else centred crop of that size */
 } orc_params;
 

@@ -110,7 +110,7 @@ class COracle:
         self.lib.orc_default_params(C.byref(p))
         return p
 
-    def gray(self, bgr: np.ndarray, shift: int = 14) -> np.ndarray:
+    def gray(self, bgr: np.ndarray, shift: int = 15) -> np.ndarray:
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         h, w, _ = bgr.shape
         out = np.empty((h, w), np.uint8)
@@ -199,7 +199,7 @@ def metrics_to_dict(m: OrcMetrics) -> dict:
 # --------------------------------------------------------------------------- numpy / scipy mirror
 
 
-def np_gray(bgr: np.ndarray, shift: int = 14) -> np.ndarray:
+def np_gray(bgr: np.ndarray, shift: int = 15) -> np.ndarray:
     """cv2.cvtColor(BGR2GRAY), passive_checker.py:100 (fixed point, round to nearest)."""
     b = bgr[..., 0].astype(np.int64)
     g = bgr[..., 1].astype(np.int64)
@@ -322,7 +322,7 @@ def np_lbp_uniform(gray: np.ndarray, P: int = 8, R: float = 1.0) -> np.ndarray:
 
 
 def np_analyze_frame(bgr: np.ndarray, P: int = 8, R: float = 1.0, low: int = 50, high: int = 150,
-                     shift: int = 14) -> dict:
+                     shift: int = 15) -> dict:
     """The five metrics of passive_checker.py:96-131 with numpy doing every reduction the reference gives it."""
     gray = np_gray(bgr, shift)
     lbp = np_lbp_uniform(gray, P, R).astype(np.float64)

@@ -13,9 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SIFT_TEXTURE_LIB") or os.path.join(_HERE, "libsift_texture.so")
 
 STX_OK = 0
+FLAG_FFT_F64 = 1
 LBP_MAX_BINS = 26
-N_KERNELS = 8
-KERNEL_NAMES = ("gray", "stencil", "lbp_generic", "hysteresis", "fft_rows", "fft_cols", "reduce", "synth")
+N_KERNELS = 10
+KERNEL_NAMES = ("gray", "stencil", "lbp_generic", "hysteresis", "fft_rows", "fft_cols", "reduce", "synth", "quality",
+                "extended")
 
 EXPORTS = (
     "stx_version", "stx_create", "stx_destroy", "stx_last_error", "stx_backend", "stx_default_params",
@@ -42,6 +44,7 @@ class StxParams(C.Structure):
         ("fft_h", C.c_int),
         ("fft_w", C.c_int),
         ("quality_stats", C.c_int),
+        ("fft_exact", C.c_int),
     ]
 
 
@@ -55,7 +58,7 @@ class StxMetrics(C.Structure):
         ("texture_score", C.c_double),
         ("lbp_hist", C.c_uint32 * LBP_MAX_BINS),
         ("edge_count", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("flags", C.c_uint32),
         ("absdiff_sum", C.c_uint64),
         ("hp_sum", C.c_uint64),
         ("hp_sumsq", C.c_uint64),
@@ -90,7 +93,8 @@ class StxExtended(C.Structure):
 
 
 class StxTiming(C.Structure):
-    _fields_ = [("ms", C.c_double * N_KERNELS), ("launches", C.c_uint64 * N_KERNELS), ("frames", C.c_uint64)]
+    _fields_ = [("ms", C.c_double * N_KERNELS), ("launches", C.c_uint64 * N_KERNELS), ("frames", C.c_uint64),
+                ("fft64_frames", C.c_uint64)]
 
 
 _lib = None

@@ -80,6 +80,9 @@ struct stx_ctx {
     std::string err;
     Slot slot[N_SLOTS];
     DevBuf codes, plane, taps, prep_out, tie;
+    DevBuf spec64, scratch64, part64;  // double-precision transform of single frames
+    std::map<int, void*> twiddles64;
+    uint64_t fft64_frames = 0;         // frames whose spectral statistic was recomputed in double precision
     int tie_ncls = 0;
     double tie_key[4] = {0, 0, 0, 0};  // the offsets the tie tables were built for
     std::map<int, float2*> twiddles;
@@ -186,6 +189,22 @@ int get_twiddles(stx_ctx* c, int n, float2** out) {
     return STX_OK;
 }
 
+int get_twiddles64(stx_ctx* c, int n, void** out) {
+    auto it = c->twiddles64.find(n);
+    if (it != c->twiddles64.end()) { *out = it->second; return STX_OK; }
+    std::vector<double2> h((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_double2(cos(a), sin(a));
+    }
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(double2) * (size_t)n));
+    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
+    c->twiddles64[n] = d;
+    *out = d;
+    return STX_OK;
+}
+
 // numpy.round(x, 5) = rint(x * 1e5) / 1e5; the sample offsets of skimage's local_binary_pattern
 int lbp_offsets(int P, double R, LbpOffsets* o) {
     if (P < 1 || P > 24) return -1;
@@ -215,6 +234,7 @@ void finalize(const FrameAcc& a, const Geom& g, int P, stx_metrics* m) {
     m->n_pixels = n;
     for (int k = 0; k < STX_LBP_MAX_BINS; ++k) m->lbp_hist[k] = a.lbp_hist[k];
     m->edge_count = a.edge_count;
+    m->flags = a.pad0 ? STX_FLAG_FFT_F64 : 0u;
     m->absdiff_sum = a.absdiff_sum;
     m->hp_sum = a.hp_sum;
     m->hp_sumsq = a.hp_sumsq;
@@ -237,6 +257,22 @@ void finalize(const FrameAcc& a, const Geom& g, int P, stx_metrics* m) {
     const double fv = a.fft_sumsq / nf - fm * fm;
     m->frequency_anomaly = fv > 0.0 ? sqrt(fv) : 0.0;
     m->texture_score = texture_score(*m);
+}
+
+// Whether the fp32 transform's rounding noise can move the spectral statistic of this frame by more than 2e-5 of
+// its value (the parity budget is 1e-4).  Bins well above the noise are perturbed by a relative, zero-mean amount
+// that cancels in the sums; a bin near zero is not: its ln(|F|+1) rises by up to err/(|F|+1).  With l = ln(|F|+1)
+// and mean mu, the variance then changes by at most 2 err sum_small |mu - l| / (|F|+1) / N to first order, which
+// the column pass's t1 = sum 1/(|F|+1) and t2 = sum l/(|F|+1) over the small bins give.
+bool fft_needs_f64(const FrameAcc& a, const Geom& g) {
+    if (!(a.fft_t1 > 0.0)) return false;
+    const double nf = (double)g.fh * (double)g.fw;
+    const double mu = a.fft_sum / nf;
+    const double var = a.fft_sumsq / nf - mu * mu;
+    const double lmax = log((double)fft_small_threshold(g.fh, g.fw) + 1.0);
+    const double dev = mu >= lmax ? mu * a.fft_t1 - a.fft_t2 : lmax * a.fft_t1;
+    const double dvar = 2.0 * fft_f32_bin_error(g.fh, g.fw) * dev / nf;
+    return dvar > 4e-5 * (var > 0.0 ? var : 0.0);  // d(std)/std = dvar / (2 var)
 }
 
 // Population variances of the Laplacian image and of the gray image (main.py:209-210) from exact integer sums.
@@ -279,6 +315,7 @@ int check_params(stx_ctx* c, const stx_params& p) {
     if (p.gray_shift != 14 && p.gray_shift != 15) return fail(c, STX_ERR_INVALID, "gray_shift must be 14 or 15");
     if (p.canny_low < 0 || p.canny_high < 0) return fail(c, STX_ERR_INVALID, "canny thresholds must be >= 0");
     if (p.fft_h < 0 || p.fft_w < 0) return fail(c, STX_ERR_INVALID, "fft crop must be >= 0");
+    if (p.fft_exact < -1 || p.fft_exact > 1) return fail(c, STX_ERR_INVALID, "fft_exact must be -1, 0 or 1");
     return STX_OK;
 }
 
@@ -364,7 +401,7 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
     const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
     {
         Span sp(c, &sl.spans, STX_K_REDUCE, 1, s);
-        launch_frame_reduce(s, (const uint32_t*)sl.spart.p, lbp81, (const uint32_t*)sl.tiles.p, (const double2*)sl.part.p,
+        launch_frame_reduce(s, (const uint32_t*)sl.spart.p, lbp81, (const uint32_t*)sl.tiles.p, (const FftPart*)sl.part.p,
                             pr.lay.parts_per_frame, sl.F, pr.g, (FrameAcc*)sl.acc.p);
         sp.end();
     }
@@ -390,7 +427,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     if ((rc = ensure(c, sl.strong, bm)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.cand, bm)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(double2))) != STX_OK) return rc;
+    if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(FftPart))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.tiles, (size_t)F * g.bm_tiles * g.bm_words * sizeof(uint32_t))) != STX_OK) return rc;
     if ((rc = ensure(c, sl.tflag, (size_t)2 * F * g.bm_tiles * g.bm_words)) != STX_OK) return rc;
     if ((rc = ensure(c, sl.spart, (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t))) != STX_OK) return rc;
@@ -446,7 +483,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     }
     if (p.quality_stats) {
         if ((rc = ensure(c, sl.qpart, quality_part_bytes(g, F))) != STX_OK) return rc;
-        Span sp(c, &sl.spans, STX_K_SYNTH, 2, s);
+        Span sp(c, &sl.spans, STX_K_QUALITY, 2, s);
         launch_quality(s, (const uint8_t*)sl.gray.p, F, g, (unsigned long long*)sl.qpart.p, acc);
         sp.end();
     }
@@ -454,7 +491,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         if ((rc = ensure(c, sl.xpart, extended_part_bytes(g, F))) != STX_OK) return rc;
         if ((rc = ensure(c, sl.lpart, lbp_generic_part_bytes(g, F))) != STX_OK) return rc;
         {
-            Span sp(c, &sl.spans, STX_K_SYNTH, 2, s);
+            Span sp(c, &sl.spans, STX_K_EXTENDED, 2, s);
             launch_extended(s, (const uint8_t*)sl.gray.p, F, g, p.canny_high, (unsigned long long*)sl.xpart.p, acc);
             sp.end();
         }
@@ -480,7 +517,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         {
             Span sp(c, &sl.spans, STX_K_FFT_COLS, 1, sf);
             launch_fft_cols(sf, (const uint8_t*)sl.gray.p, (const float2*)sl.spec.p, F, g, lay, pr.plan_h, pr.tw_h,
-                            (double2*)sl.part.p);
+                            (FftPart*)sl.part.p, fft_small_threshold(g.fh, g.fw));
             sp.end();
         }
         if (sf != s) {
@@ -521,6 +558,37 @@ void finalize_extended(const FrameAcc& a, const Geom& g, stx_extended* x) {
     x->blockiness = me / (mi + 1e-10);
 }
 
+// Recomputes fft_sum / fft_sumsq of the listed frames of a finished chunk in double precision (the chunk's gray
+// planes are still in the slot).  One frame at a time: this is the path of rare, synthetic-looking frames.
+int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const std::vector<int>& frames) {
+    const Geom& g = pr.g;
+    Fft64Work w;
+    fft64_sizes(g, &w.spec_bytes, &w.scratch_bytes, &w.part_bytes);
+    int rc;
+    if ((rc = ensure(c, c->spec64, w.spec_bytes)) != STX_OK) return rc;
+    if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes)) != STX_OK) return rc;
+    if ((rc = ensure(c, c->part64, w.part_bytes)) != STX_OK) return rc;
+    w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
+    void *tw_w = nullptr, *tw_h = nullptr;
+    if ((rc = get_twiddles64(c, g.fw, &tw_w)) != STX_OK) return rc;
+    if ((rc = get_twiddles64(c, g.fh, &tw_h)) != STX_OK) return rc;
+    std::vector<double2> part((size_t)g.fwh);
+    for (int f : frames) {
+        launch_fft64(c->stream, (const uint8_t*)sl.gray.p + (size_t)f * g.grows * g.gpitch, g, pr.plan_w, pr.plan_h, tw_w,
+                     tw_h, w);
+        HIPCHK(c, hipMemcpyAsync(part.data(), w.part, w.part_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        double s = 0.0, s2 = 0.0;  // fixed order: reproducible
+        for (int k = 0; k < g.fwh; ++k) { s += part[k].x; s2 += part[k].y; }
+        sl.acc_host[f].fft_sum = s;
+        sl.acc_host[f].fft_sumsq = s2;
+        sl.acc_host[f].pad0 = 1u;
+    }
+    c->fft64_frames += frames.size();
+    return STX_OK;
+}
+
 int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx_extended* ext = nullptr) {
     HIPCHK(c, hipEventSynchronize(sl.done));
     while (*sl.changed_host != 0) {
@@ -534,9 +602,20 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx
         HIPCHK(c, hipEventSynchronize(sl.done));
     }
     HIPCHK(c, hipGetLastError());
-    if (c->timing) {
+    // spans recorded at enqueue time are collected even if timing has been switched off since (their events go
+    // back to the pool)
+    if (!sl.spans.empty()) {
         collect_spans(c, sl.spans);
         c->tacc.frames += (uint64_t)sl.F;
+    }
+    if (out && pr.p.fft_exact >= 0) {
+        std::vector<int> redo;
+        for (int i = 0; i < sl.F; ++i)
+            if (pr.p.fft_exact > 0 || fft_needs_f64(sl.acc_host[i], pr.g)) redo.push_back(i);
+        if (!redo.empty()) {
+            const int rc = refine_fft64(c, sl, pr, redo);
+            if (rc != STX_OK) return rc;
+        }
     }
     if (out)
         for (int i = 0; i < sl.F; ++i) {
@@ -586,10 +665,11 @@ void stx_default_params(stx_params* p) {
     p->lbp_radius = 1.0;
     p->canny_low = 50;
     p->canny_high = 150;
-    p->gray_shift = 14;
+    p->gray_shift = 15;
     p->fft_h = 0;
     p->fft_w = 0;
     p->quality_stats = 0;
+    p->fft_exact = 0;
 }
 
 static thread_local std::string g_create_err = "null context";
@@ -656,6 +736,10 @@ int stx_destroy(stx_ctx* c) {
     if (c->plane.p) (void)hipFree(c->plane.p);
     if (c->taps.p) (void)hipFree(c->taps.p);
     if (c->tie.p) (void)hipFree(c->tie.p);
+    if (c->spec64.p) (void)hipFree(c->spec64.p);
+    if (c->scratch64.p) (void)hipFree(c->scratch64.p);
+    if (c->part64.p) (void)hipFree(c->part64.p);
+    for (auto& kv : c->twiddles64) (void)hipFree(kv.second);
     if (c->prep_out.p) (void)hipFree(c->prep_out.p);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -1050,7 +1134,11 @@ int stx_set_timing(stx_ctx* c, int enabled) {
 int stx_get_timing(stx_ctx* c, stx_timing* out, int reset) {
     if (!c || !out) return STX_ERR_INVALID;
     *out = c->tacc;
-    if (reset) memset(&c->tacc, 0, sizeof(c->tacc));
+    out->fft64_frames = c->fft64_frames;
+    if (reset) {
+        memset(&c->tacc, 0, sizeof(c->tacc));
+        c->fft64_frames = 0;
+    }
     return STX_OK;
 }
 

@@ -703,7 +703,8 @@ struct ColsArgs {
     int cbw, nkb;
     int cbw_log2;
     const float2* tw;
-    double2* part;  // [frame][nkb*cbw]
+    FftPart* part;  // [frame][nkb*cbw]
+    float small;    // bins below this magnitude also go into the t1 / t2 sums
     const uint8_t* gray0;  // gray level at the origin of frame 0's transformed region; frames gstride apart
     int64_t gstride;
 };
@@ -796,18 +797,26 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     // the last pass hands its outputs straight to the log-magnitude reduction
     struct LogMagSink {
         double ls = 0.0, ls2 = 0.0;
-        float dc_fix;
+        float t1 = 0.f, t2 = 0.f;
+        float dc_fix, small;
         bool dc_col;
         __device__ __forceinline__ void operator()(int y, float2 v) {
             if (dc_col && y == 0) v.x += dc_fix;
             // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
             // the statistic; the sums stay in fp64 because the variance is a small difference
             const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
-            const double l = (double)(__builtin_amdgcn_logf(mag + 1.0f) * 0.69314718055994530942f);
+            const float lf = __builtin_amdgcn_logf(mag + 1.0f) * 0.69314718055994530942f;
+            const double l = (double)lf;
             ls += l;
             ls2 += l * l;
+            if (__any(mag < small)) {  // rare on camera-like content: the wave skips it as a whole
+                const float r = mag < small ? __builtin_amdgcn_rcpf(mag + 1.0f) : 0.f;
+                t1 += r;
+                t2 += r * lf;
+            }
         }
     } sink;
+    sink.small = a.small;
     sink.dc_col = (k == 0);
     sink.dc_fix = sink.dc_col ? (float)a.gray0[(int64_t)frame * a.gstride] * (float)N * (float)a.fw : 0.f;
     if constexpr (ColsDirect<P>::ok) {
@@ -817,16 +826,19 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
         transform_to<P>(buf, a.tw, t, sink);
     }
     double ls = sink.ls, ls2 = sink.ls2;
-    if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; }  // columns past the half spectrum hold no data
+    float t1 = sink.t1, t2 = sink.t2;
+    if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; t1 = 0.f; t2 = 0.f; }  // columns past the half spectrum hold no data
 #pragma unroll
     for (int o = LPT / 2; o > 0; o >>= 1) {
         ls += __shfl_xor(ls, o, 64);
         ls2 += __shfl_xor(ls2, o, 64);
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
     }
     if (t == 0) {
         // columns 0 and (even W) W/2 are their own mirror images; every other column stands for two
         const double wgt = (k >= a.fwh) ? 0.0 : ((k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0);
-        a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = make_double2(wgt * ls, wgt * ls2);
+        a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = FftPart{wgt * ls, wgt * ls2, wgt * (double)t1, wgt * (double)t2};
     }
 }
 
@@ -964,11 +976,11 @@ bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, cons
 }
 
 bool launch_fft_cols_fast(hipStream_t s, const uint8_t* gray0, int64_t gstride, const float2* spec, int n_frames,
-                          const Geom& g, const FftLayout& lay, const float2* tw, double2* part) {
+                          const Geom& g, const FftLayout& lay, const float2* tw, FftPart* part, float small) {
     ColsArgs a;
     a.gray0 = gray0; a.gstride = gstride;
     a.spec = spec; a.fw = g.fw; a.fwh = g.fwh; a.cbw = lay.cbw; a.nkb = lay.nkb; a.cbw_log2 = __builtin_ctz(lay.cbw);
-    a.tw = tw; a.part = part;
+    a.tw = tw; a.part = part; a.small = small;
     switch (g.fh) {
 #define X(N, A, B, C, D, L)                                    \
     case N:                                                    \

@@ -1,0 +1,133 @@
+// Generic LDS Stockham passes shared by the fp32 kernels (stx_fft.hip) and the fp64 kernels (stx_fft64.hip):
+// radix 4/2/3/5 butterflies, any other prime factor by a direct small DFT.
+#pragma once
+
+#include "stx_internal.h"
+
+namespace stx {
+
+template <class T>
+struct alignas(2 * sizeof(T)) Cpx {
+    T x, y;
+};
+template <class T>
+__device__ __forceinline__ Cpx<T> mk(T x, T y) { return Cpx<T>{x, y}; }
+template <class T>
+__device__ __forceinline__ Cpx<T> cmul(Cpx<T> a, Cpx<T> b) { return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class T>
+__device__ __forceinline__ Cpx<T> cadd(Cpx<T> a, Cpx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <class T>
+__device__ __forceinline__ Cpx<T> csub(Cpx<T> a, Cpx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+// multiply by -i
+template <class T>
+__device__ __forceinline__ Cpx<T> cmul_mi(Cpx<T> a) { return mk<T>(a.y, -a.x); }
+
+// One Stockham pass of radix R over nb transforms of length n.
+// in/out: [nb][n] (LDS or global memory); ns = product of the radices already applied; tw[j] = exp(-2 pi i j / n).
+template <class T>
+__device__ void fft_pass(const Cpx<T>* __restrict__ in, Cpx<T>* __restrict__ out, int n, int R, int ns, int nb,
+                         const Cpx<T>* __restrict__ tw, int tid, int nthreads) {
+    typedef Cpx<T> C;
+    const int m = n / R;            // butterflies per transform
+    const int twstep = n / (ns * R);
+    if (R != 2 && R != 3 && R != 4 && R != 5) {
+        // direct DFT of size R on the twiddled inputs (rare sizes only): one output per thread and step, so
+        // that a prime length (a single pass with one butterfly) still spreads over the workgroup
+        for (int b = 0; b < nb; ++b) {
+            const C* ib = in + b * n;
+            C* ob = out + b * n;
+            for (int idx = tid; idx < m * R; idx += nthreads) {
+                const int q = idx / m, j = idx - q * m;
+                const int k = j % ns;
+                const int o = (j - k) * R + k;
+                const int t1 = k * twstep;
+                C accv = mk<T>(0, 0);
+                long e = 0;  // (r*t1 + r*q*m) mod n
+                const long step = ((long)t1 + (long)q * m) % n;
+                for (int r = 0; r < R; ++r) {
+                    accv = cadd(accv, cmul(ib[j + r * m], tw[e]));
+                    e += step;
+                    if (e >= n) e -= n;
+                }
+                ob[o + q * ns] = accv;
+            }
+        }
+        return;
+    }
+    for (int b = 0; b < nb; ++b) {
+        const C* ib = in + b * n;
+        C* ob = out + b * n;
+        for (int j = tid; j < m; j += nthreads) {
+            const int k = j % ns;
+            const int o = (j - k) * R + k;
+            const int t1 = k * twstep;
+            if (R == 4) {
+                C v0 = ib[j], v1 = ib[j + m], v2 = ib[j + 2 * m], v3 = ib[j + 3 * m];
+                if (k) {
+                    v1 = cmul(v1, tw[t1]);
+                    v2 = cmul(v2, tw[2 * t1]);
+                    v3 = cmul(v3, tw[3 * t1]);
+                }
+                const C a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), a3 = cmul_mi(csub(v1, v3));
+                ob[o] = cadd(a0, a2);
+                ob[o + ns] = cadd(a1, a3);
+                ob[o + 2 * ns] = csub(a0, a2);
+                ob[o + 3 * ns] = csub(a1, a3);
+            } else if (R == 2) {
+                C v0 = ib[j], v1 = ib[j + m];
+                if (k) v1 = cmul(v1, tw[t1]);
+                ob[o] = cadd(v0, v1);
+                ob[o + ns] = csub(v0, v1);
+            } else if (R == 3) {
+                C v0 = ib[j], v1 = ib[j + m], v2 = ib[j + 2 * m];
+                if (k) {
+                    v1 = cmul(v1, tw[t1]);
+                    v2 = cmul(v2, tw[2 * t1]);
+                }
+                const C s = cadd(v1, v2), d = csub(v1, v2);
+                const C h = mk<T>(v0.x - (T)0.5 * s.x, v0.y - (T)0.5 * s.y);
+                const T c = (T)0.86602540378443864676;
+                const C r = mk<T>(c * d.y, -c * d.x);
+                ob[o] = cadd(v0, s);
+                ob[o + ns] = cadd(h, r);
+                ob[o + 2 * ns] = csub(h, r);
+            } else if (R == 5) {
+                C v0 = ib[j], v1 = ib[j + m], v2 = ib[j + 2 * m], v3 = ib[j + 3 * m], v4 = ib[j + 4 * m];
+                if (k) {
+                    v1 = cmul(v1, tw[t1]);
+                    v2 = cmul(v2, tw[2 * t1]);
+                    v3 = cmul(v3, tw[3 * t1]);
+                    v4 = cmul(v4, tw[4 * t1]);
+                }
+                const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+                const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;
+                const C a1 = cadd(v1, v4), a2 = cadd(v2, v3), b1 = csub(v1, v4), b2 = csub(v2, v3);
+                const C p1 = mk<T>(v0.x + c1 * a1.x + c2 * a2.x, v0.y + c1 * a1.y + c2 * a2.y);
+                const C p2 = mk<T>(v0.x + c2 * a1.x + c1 * a2.x, v0.y + c2 * a1.y + c1 * a2.y);
+                const C q1 = cmul_mi(mk<T>(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+                const C q2 = cmul_mi(mk<T>(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+                ob[o] = mk<T>(v0.x + a1.x + a2.x, v0.y + a1.y + a2.y);
+                ob[o + ns] = cadd(p1, q1);
+                ob[o + 2 * ns] = cadd(p2, q2);
+                ob[o + 3 * ns] = csub(p2, q2);
+                ob[o + 4 * ns] = csub(p1, q1);
+            }
+        }
+    }
+}
+
+// runs the whole plan; returns the buffer that holds the result
+template <class T>
+__device__ Cpx<T>* fft_run(Cpx<T>* a, Cpx<T>* b, const FftPlan& plan, int nb, const Cpx<T>* tw, int tid, int nthreads) {
+    int ns = 1;
+    for (int p = 0; p < plan.npass; ++p) {
+        const int R = plan.radix[p];
+        fft_pass<T>(a, b, plan.n, R, ns, nb, tw, tid, nthreads);
+        __syncthreads();
+        Cpx<T>* t = a; a = b; b = t;
+        ns *= R;
+    }
+    return a;
+}
+
+}  // namespace stx

@@ -277,10 +277,10 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
 // hysteresis tile counts -> edge count, FFT column partials -> log-magnitude sums.
 __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __restrict__ spart, int stiles,
                                                            int lbp_from_tiles, const uint32_t* __restrict__ tile_count,
-                                                           int htiles, const double2* __restrict__ fpart, int nfparts,
+                                                           int htiles, const FftPart* __restrict__ fpart, int nfparts,
                                                            FrameAcc* __restrict__ acc) {
     __shared__ unsigned long long red[16][17];
-    __shared__ double dred[2][4];
+    __shared__ double dred[4][4];
     __shared__ uint32_t ered[4];
     const int frame = blockIdx.x, tid = threadIdx.x;
     // 16 quantities x 16 tile lanes
@@ -292,19 +292,26 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
     }
     uint32_t e = 0;
     for (int i = tid; i < htiles; i += 256) e += tile_count[(int64_t)frame * htiles + i];
-    double fs = 0.0, fs2 = 0.0;
+    double fs = 0.0, fs2 = 0.0, ft1 = 0.0, ft2 = 0.0;
     for (int i = tid; i < nfparts; i += 256) {
-        const double2 p = fpart[(int64_t)frame * nfparts + i];
-        fs += p.x;
-        fs2 += p.y;
+        const FftPart p = fpart[(int64_t)frame * nfparts + i];
+        fs += p.s;
+        fs2 += p.s2;
+        ft1 += p.t1;
+        ft2 += p.t2;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         e += __shfl_xor(e, o, 64);
         fs += __shfl_xor(fs, o, 64);
         fs2 += __shfl_xor(fs2, o, 64);
+        ft1 += __shfl_xor(ft1, o, 64);
+        ft2 += __shfl_xor(ft2, o, 64);
     }
-    if ((tid & 63) == 0) { ered[tid >> 6] = e; dred[0][tid >> 6] = fs; dred[1][tid >> 6] = fs2; }
+    if ((tid & 63) == 0) {
+        ered[tid >> 6] = e;
+        dred[0][tid >> 6] = fs; dred[1][tid >> 6] = fs2; dred[2][tid >> 6] = ft1; dred[3][tid >> 6] = ft2;
+    }
     __syncthreads();
     FrameAcc* fa = acc + frame;
     if (tid < 14) {
@@ -321,6 +328,8 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
         fa->edge_count = ered[0] + ered[1] + ered[2] + ered[3];
         fa->fft_sum = ((dred[0][0] + dred[0][1]) + dred[0][2]) + dred[0][3];
         fa->fft_sumsq = ((dred[1][0] + dred[1][1]) + dred[1][2]) + dred[1][3];
+        fa->fft_t1 = ((dred[2][0] + dred[2][1]) + dred[2][2]) + dred[2][3];
+        fa->fft_t2 = ((dred[3][0] + dred[3][1]) + dred[3][2]) + dred[3][3];
     }
 }
 
@@ -351,7 +360,7 @@ void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigne
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
-                         const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc) {
+                         const FftPart* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc) {
     hipLaunchKernelGGL(frame_reduce_kernel, dim3(n_frames), dim3(256), 0, s, spart, g.tiles_x * g.tiles_y,
                        lbp_from_tiles ? 1 : 0, tile_count, g.bm_tiles * g.bm_words, fpart, nfparts, acc);
 }

@@ -21,6 +21,7 @@ struct FrameAcc {
     unsigned long long gray_sum;
     double fft_sum;
     double fft_sumsq;
+    double fft_t1, fft_t2;  // sums over the near-zero bins of the spectrum (FftPart)
     // frame-quality sums (only filled when stx_params.quality_stats is set)
     long long lap_sum;
     unsigned long long lap_sumsq;
@@ -67,6 +68,15 @@ struct FftPlan {
     int radix[FFT_MAX_PASSES];
 };
 
+// Partial sums of one spectrum column (weighted twice where the column stands for its mirror image too).
+// l = ln(|F|+1).  t1, t2 cover only the bins with |F| < the `small` threshold of the launch: those are the bins
+// whose value the fp32 rounding noise of the transform can change to first order, and
+// mean(l) * t1 - t2 = sum (mean(l) - l) / (|F|+1) bounds what that does to the variance of l.
+struct FftPart {
+    double s, s2;   // sum l, sum l^2
+    double t1, t2;  // sum 1/(|F|+1), sum l/(|F|+1) over the small bins
+};
+
 // ---- launchers (each file owns its kernels) ----
 void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
                  const Geom& g, int shift, uint8_t* gray);
@@ -98,12 +108,12 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
 void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
-                         const double2* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
+                         const FftPart* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);
 
-// Real 2-D FFT of the (cropped) gray plane minus 128, log-magnitude statistics.
+// Real 2-D FFT of the (cropped) gray plane minus its first gray level, log-magnitude statistics.
 // spec: [n_frames][nkb][fh][cbw] float2 half spectrum in column blocks.
-// part: [n_frames][parts_per_frame] double2 partial (sum, sum of squares).
+// part: [n_frames][parts_per_frame] FftPart.
 struct FftLayout {
     int cbw, nkb;
     int parts_per_frame;
@@ -113,7 +123,25 @@ FftLayout fft_choose_layout(const Geom& g);
 void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                      const FftPlan& plan, const float2* tw, float2* spec);
 void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int n_frames, const Geom& g,
-                     const FftLayout& lay, const FftPlan& plan, const float2* tw, double2* part);
+                     const FftLayout& lay, const FftPlan& plan, const float2* tw, FftPart* part, float small);
+// Bound on the absolute error of one bin of the fp32 transform of an fh x fw region of 8-bit pixels, and the
+// magnitude below which a bin counts as small.
+double fft_f32_bin_error(int fh, int fw);
+inline float fft_small_threshold(int fh, int fw) { return (float)(64.0 * fft_f32_bin_error(fh, fw)); }
+
+// The same transform and statistic in double precision for single frames (stx_fft64.hip): used for the frames whose
+// spectrum has enough near-zero bins that fp32 rounding noise would show in the statistic.
+struct Fft64Work {
+    void* spec = nullptr;     // [fh][fwh] double2
+    void* scratch = nullptr;  // second pass buffer of the workgroups when it does not fit LDS
+    void* part = nullptr;     // [fwh] double2 (sum, sum of squares) per column, weighted
+    size_t spec_bytes = 0, scratch_bytes = 0, part_bytes = 0;
+};
+void fft64_sizes(const Geom& g, size_t* spec_bytes, size_t* scratch_bytes, size_t* part_bytes);
+// gray_frame: the padded gray plane of ONE frame; tw_w / tw_h: double2 tables exp(-2 pi i k / n) of fw / fh entries
+void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h,
+                  const void* tw_w, const void* tw_h, const Fft64Work& w);
+hipError_t fft64_set_lds_limits();
 // compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
 bool fft_fast_available(int n);
 int fft_fast_stride(int n);
@@ -122,7 +150,7 @@ hipError_t fft_fast_init();
 bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                           const float2* tw, float2* spec);
 bool launch_fft_cols_fast(hipStream_t s, const uint8_t* gray0, int64_t gstride, const float2* spec, int n_frames,
-                          const Geom& g, const FftLayout& lay, const float2* tw, double2* part);
+                          const Geom& g, const FftLayout& lay, const float2* tw, FftPart* part, float small);
 
 // Laplacian / gray-square sums per frame into acc[] (stx_quality.hip); part holds quality_part_bytes.
 size_t quality_part_bytes(const Geom& g, int n_frames);

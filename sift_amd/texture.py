@@ -216,7 +216,7 @@ class TextureContext:
     def get_timing(self, reset: bool = False) -> dict:
         t = StxTiming()
         self._check(self.lib.stx_get_timing(self.handle, C.byref(t), 1 if reset else 0), "stx_get_timing")
-        return {"frames": int(t.frames),
+        return {"frames": int(t.frames), "fft64_frames": int(t.fft64_frames),
                 "kernels": {name: {"ms": float(t.ms[i]), "launches": int(t.launches[i])}
                             for i, name in enumerate(_lib.KERNEL_NAMES)}}
 

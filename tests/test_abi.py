@@ -24,10 +24,26 @@ def test_header_symbols_exported():
     assert set(names) == set(_lib.EXPORTS)
 
 
-def test_struct_layout_matches_header():
-    assert C.sizeof(_lib.StxMetrics) == 6 * 8 + 26 * 4 + 8 + 5 * 8 + 2 * 8 + 5 * 8
-    assert C.sizeof(_lib.StxParams) == 40
-    assert C.sizeof(_lib.StxTiming) == 8 * 8 + 8 * 8 + 8
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof as a C compiler sees include/sift_texture.h against the ctypes mirrors."""
+    import subprocess
+    structs = {"stx_params": _lib.StxParams, "stx_metrics": _lib.StxMetrics, "stx_timing": _lib.StxTiming,
+               "stx_extended": _lib.StxExtended}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sift_texture.h"\nint main(void) {\n'
+                   + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_version_and_defaults():
@@ -37,7 +53,7 @@ def test_version_and_defaults():
     lib.stx_default_params(C.byref(p))
     # the literals of /root/reference/app/passive_checker.py:103, :116
     assert (p.lbp_points, p.lbp_radius, p.canny_low, p.canny_high, p.gray_shift, p.fft_h, p.fft_w) == (
-        8, 1.0, 50, 150, 14, 0, 0)
+        8, 1.0, 50, 150, 15, 0, 0)
 
 
 def test_score_summary_matches_numpy_mean():

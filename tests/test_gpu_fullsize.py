@@ -52,6 +52,29 @@ def test_full_frame_vs_oracle(ctx, coracle, kind, h, w):
     assert np.array_equal(edges, coracle.canny(g)[0])
 
 
+@pytest.mark.parametrize("kind", ["ramp", "step", "edge"])
+def test_1080p_structured_frequency_statistic(ctx, coracle, kind):
+    """Noise-free structure at the headline frame size: ramp, bars with +-1 noise, a constant with one edge."""
+    h, w = 1080, 1920
+    if kind == "edge":
+        g = np.full((h, w), 80, np.uint8)
+        g[:, 1000:] = 140
+        f = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    else:
+        f = synth_frame(kind, SEED + 2, 2, 3, h, w)
+    r = ctx.analyze_frames([f])[0]
+    m = coracle.analyze_frame(f)
+    assert _ints(r) == _ints(m)
+    for a, b, k in zip(_floats(r), _floats(m), O.METRIC_KEYS + ("texture_score",)):
+        assert a == pytest.approx(b, rel=1e-4, abs=1e-9), k
+    # larger than the LDS holds two fp64 pass buffers for: the second one goes through global memory
+    if kind == "ramp":
+        wide = np.ascontiguousarray(f[:6, :, :].repeat(4, axis=1)[:, :5120])  # 6 x 5120
+        p = ctx.default_params(); p.fft_exact = 1
+        want = float(np.std(np.log(np.abs(np.fft.fft2(coracle.gray(wide).astype(np.float64))) + 1)))
+        assert ctx.analyze_frames([wide], p)[0].frequency_anomaly == pytest.approx(want, rel=1e-9)
+
+
 @pytest.mark.parametrize("h,w,cell", PATCHWORK_CASES)
 def test_flat_patches_vs_skimage_golden(ctx, h, w, cell):
     """Flat patches: every interior pixel is an exact tie of the four diagonal samples, resolved from the
