@@ -107,6 +107,7 @@ def main() -> None:
     ap.add_argument("--pipeline", action="store_true",
                     help="two clips in flight through stx_submit_batch_device / stx_wait instead of one blocking "
                          "call per step")
+    ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = the library's choice)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the CPU baseline legs")
     args = ap.parse_args()
 
@@ -148,6 +149,8 @@ def main() -> None:
     fh = fw = cfg["fft"]
     fh, fw = (fh or h), (fw or w)
     ctx = TextureContext(local_rank)
+    if args.chunk:
+        ctx.set_chunk_frames(args.chunk)
     params = None
     if cfg["fft"]:
         params = ctx.default_params()
