@@ -125,6 +125,20 @@ int stx_analyze_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames,
                              int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
                              stx_metrics* out);
 
+/* stx_analyze_batch_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc); it has no counterpart in the reference.  The call itself allocates nothing, on
+ * the device or the host: every intermediate (gray planes, edge maps, spectra, partial sums, twiddle tables, the
+ * fp64 workspace of stx_params.fft_exact) lives in a static device array of STX_NOALLOC_SCRATCH_BYTES that each GPU
+ * the library runs on holds until the process ends; streams, events and pinned staging are created by stx_create.
+ * Frames go through the array at most 64 at a time.  Limits: LBP at (P=8, R=1) only, no quality_stats, and one
+ * frame's workspace must fit the array (1080p and 4K frames do; STX_ERR_UNSUPPORTED with a message otherwise).
+ * Results equal stx_analyze_batch_device's.  All contexts of one GPU share the array: calls that overlap on one GPU
+ * race (one call at a time per GPU). */
+#define STX_NOALLOC_SCRATCH_BYTES (128u << 20)
+int stx_analyze_batch_device_noalloc(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w,
+                                     int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
+                                     stx_metrics* out);
+
 /* Asynchronous form of stx_analyze_batch_device (no counterpart in the reference): queues the work
  * on the GPU and returns a ticket; stx_wait(ticket) blocks until out[0..n_frames) is filled.  Up to
  * two submissions may be in flight, so the host part of one clip and the memory-bound gray pass of

@@ -21,7 +21,7 @@ KERNEL_NAMES = ("gray", "stencil", "lbp_generic", "hysteresis", "fft_rows", "fft
 
 EXPORTS = (
     "stx_version", "stx_create", "stx_destroy", "stx_last_error", "stx_backend", "stx_default_params",
-    "stx_analyze_batch", "stx_analyze_frames", "stx_analyze_batch_device", "stx_submit_batch_device", "stx_wait",
+    "stx_analyze_batch", "stx_analyze_frames", "stx_analyze_batch_device", "stx_analyze_batch_device_noalloc", "stx_submit_batch_device", "stx_wait",
     "stx_max_async_frames", "stx_score_summary",
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
     "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing",
@@ -131,6 +131,7 @@ def load() -> C.CDLL:
     L.stx_analyze_frames.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64,
                                      C.POINTER(StxParams), C.POINTER(StxMetrics)]
     L.stx_analyze_batch_device.argtypes = L.stx_analyze_batch.argtypes
+    L.stx_analyze_batch_device_noalloc.argtypes = L.stx_analyze_batch.argtypes
     L.stx_submit_batch_device.argtypes = L.stx_analyze_batch.argtypes + [C.POINTER(C.c_int)]
     L.stx_wait.argtypes = [C.c_void_p, C.c_int]
     L.stx_max_async_frames.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -28,6 +28,7 @@ constexpr int HYST_GROUP = 1;         // further launches per host check when th
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool fixed = false;  // a piece of the static scratch array: never freed, never grown
 };
 
 struct TimedSpan {
@@ -37,6 +38,19 @@ struct TimedSpan {
 };
 
 }  // namespace
+
+// Workspace of stx_analyze_batch_device_noalloc: every intermediate of that entry point lives here, so it never
+// allocates.  One copy per GPU the library runs on, held until the process ends.  Host code must not use this name
+// as an address: stx_create looks the device address up with hipGetSymbolAddress and keeps it per context.
+static __device__ __align__(256) unsigned char scratch[STX_NOALLOC_SCRATCH_BYTES];
+
+// Layout of the scratch array: four twiddle tables of STX_MAX_DIM entries, then the buffers of one chunk of frames.
+constexpr size_t NA_TW_W = 0;
+constexpr size_t NA_TW_H = NA_TW_W + (size_t)STX_MAX_DIM * sizeof(float2);
+constexpr size_t NA_TW64_W = NA_TW_H + (size_t)STX_MAX_DIM * sizeof(float2);
+constexpr size_t NA_TW64_H = NA_TW64_W + (size_t)STX_MAX_DIM * sizeof(double2);
+constexpr size_t NA_BUFFERS = NA_TW64_H + (size_t)STX_MAX_DIM * sizeof(double2);
+constexpr int NA_MAX_CHUNK = 64;  // frames per pass over the scratch array (the pinned result staging holds this many)
 
 // Everything derived from (frame size, parameters) that the kernels of one call need.
 struct Prepared {
@@ -66,6 +80,7 @@ struct Slot {
     int F = 0;
     std::vector<TimedSpan> spans;
     std::vector<uint8_t> pack;  // host rows of strided frames, packed for one linear copy
+    std::vector<int> redo;      // frames of the chunk whose transform is repeated in fp64
 };
 constexpr int N_SLOTS = 2;
 
@@ -82,7 +97,13 @@ struct stx_ctx {
     DevBuf codes, plane, taps, prep_out, tie;
     DevBuf spec64, scratch64, part64;  // double-precision transform of single frames
     std::map<int, void*> twiddles64;
+    std::vector<double2> part64_host;
     uint64_t fft64_frames = 0;         // frames whose spectral statistic was recomputed in double precision
+    // stx_analyze_batch_device_noalloc
+    uint8_t* na_base = nullptr;        // device address of this GPU's copy of the scratch array
+    Slot na;                           // its buffers point into the scratch array
+    void* na_stage = nullptr;          // pinned host staging for twiddle uploads (STX_MAX_DIM double2)
+    int na_tw_n[4] = {0, 0, 0, 0};     // lengths of the tables currently in the scratch array
     int tie_ncls = 0;
     double tie_key[4] = {0, 0, 0, 0};  // the offsets the tie tables were built for
     std::map<int, float2*> twiddles;
@@ -109,6 +130,7 @@ int fail(stx_ctx* c, int code, const std::string& msg) {
 
 int ensure(stx_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return STX_OK;
+    if (b.fixed) return fail(c, STX_ERR_NOMEM, "internal: a buffer carved from the static scratch array is too small");
     if (b.p) {
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
@@ -214,6 +236,20 @@ int lbp_offsets(int P, double R, LbpOffsets* o) {
         o->cp[i] = rint(R * cos(ang) * 100000.0) / 100000.0;
     }
     return 0;
+}
+
+// The (P=8, R=1) tables for flat neighbourhoods: built once per context (stx_create does it for the default
+// offsets, so the per-call paths find them in place).
+int ensure_tie_tables(stx_ctx* c, const LbpOffsets& off) {
+    const double key[4] = {off.rp[1], off.rp[5], off.cp[1], off.cp[3]};
+    if (c->tie.p && memcmp(key, c->tie_key, sizeof(key)) == 0) return STX_OK;
+    std::vector<uint8_t> blob;
+    build_tie_tables(off, &blob, &c->tie_ncls);
+    int rc;
+    if ((rc = ensure(c, c->tie, blob.size())) != STX_OK) return rc;
+    HIPCHK(c, hipMemcpy(c->tie.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    memcpy(c->tie_key, key, sizeof(key));
+    return STX_OK;
 }
 
 double dmin(double a, double b) { return a < b ? a : b; }
@@ -352,7 +388,7 @@ struct ChunkOpts {
 };
 
 
-int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
+int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr, bool own_twiddles = true) {
     if (!c) return STX_ERR_INVALID;
     if (params) pr->p = *params; else stx_default_params(&pr->p);
     int rc;
@@ -363,8 +399,11 @@ int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr) {
     if (!make_fft_plan(pr->g.fw, &pr->plan_w) || !make_fft_plan(pr->g.fh, &pr->plan_h))
         return fail(c, STX_ERR_UNSUPPORTED, "FFT size has too many prime factors");
     pr->lay = fft_choose_layout(pr->g);
-    if ((rc = get_twiddles(c, pr->g.fw, &pr->tw_w)) != STX_OK) return rc;
-    if ((rc = get_twiddles(c, pr->g.fh, &pr->tw_h)) != STX_OK) return rc;
+    pr->tw_w = pr->tw_h = nullptr;
+    if (own_twiddles) {
+        if ((rc = get_twiddles(c, pr->g.fw, &pr->tw_w)) != STX_OK) return rc;
+        if ((rc = get_twiddles(c, pr->g.fh, &pr->tw_h)) != STX_OK) return rc;
+    }
     if (lbp_offsets(pr->p.lbp_points, pr->p.lbp_radius, &pr->off) != 0) return fail(c, STX_ERR_INVALID, "bad lbp_points");
     return STX_OK;
 }
@@ -412,6 +451,31 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
     return STX_OK;
 }
 
+// Bytes of every device buffer a chunk of F frames needs, in the order of ChunkBuf.
+enum ChunkBuf { CB_GRAY, CB_STRONG, CB_CAND, CB_SPEC, CB_PART, CB_TILES, CB_TFLAG, CB_SPART, CB_ACC, CB_CHANGED, CB_LPART,
+                CB_QPART, CB_XPART, CB_COUNT };
+void chunk_sizes(const Prepared& pr, int F, size_t (&n)[CB_COUNT]) {
+    const Geom& g = pr.g;
+    const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
+    n[CB_GRAY] = (size_t)F * g.grows * g.gpitch;
+    n[CB_STRONG] = n[CB_CAND] = (size_t)F * g.W * g.bm_words * sizeof(unsigned long long);
+    n[CB_SPEC] = (size_t)F * pr.lay.nkb * g.fh * pr.lay.cbw * sizeof(float2);
+    n[CB_PART] = (size_t)F * pr.lay.parts_per_frame * sizeof(FftPart);
+    n[CB_TILES] = (size_t)F * g.bm_tiles * g.bm_words * sizeof(uint32_t);
+    n[CB_TFLAG] = (size_t)2 * F * g.bm_tiles * g.bm_words;
+    n[CB_SPART] = (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t);
+    n[CB_ACC] = (size_t)F * sizeof(FrameAcc);
+    n[CB_CHANGED] = (size_t)HYST_MAX_PASSES * sizeof(unsigned int);
+    n[CB_LPART] = (!lbp81 || pr.ext) ? lbp_generic_part_bytes(g, F) : 0;
+    n[CB_QPART] = pr.p.quality_stats ? quality_part_bytes(g, F) : 0;
+    n[CB_XPART] = pr.ext ? extended_part_bytes(g, F) : 0;
+}
+DevBuf* chunk_buf(Slot& sl, int i) {
+    DevBuf* b[CB_COUNT] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc,
+                           &sl.changed, &sl.lpart, &sl.qpart, &sl.xpart};
+    return b[i];
+}
+
 // Queues the whole path for F device-resident frames on the context stream; returns without
 // waiting.  finish_chunk() waits and leaves the reductions in sl.acc_host[0..F).
 int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stride, int64_t frame_stride, int F,
@@ -422,18 +486,12 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     const stx_params& p = pr.p;
     const FftLayout& lay = pr.lay;
     int rc;
-    if ((rc = ensure(c, sl.gray, (size_t)F * g.grows * g.gpitch)) != STX_OK) return rc;
-    const size_t bm = (size_t)F * g.W * g.bm_words * sizeof(unsigned long long);
-    if ((rc = ensure(c, sl.strong, bm)) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.cand, bm)) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.spec, (size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.part, (size_t)F * lay.parts_per_frame * sizeof(FftPart))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.tiles, (size_t)F * g.bm_tiles * g.bm_words * sizeof(uint32_t))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.tflag, (size_t)2 * F * g.bm_tiles * g.bm_words)) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.spart, (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.acc, (size_t)F * sizeof(FrameAcc))) != STX_OK) return rc;
-    if ((rc = ensure(c, sl.changed, (size_t)HYST_MAX_PASSES * sizeof(unsigned int))) != STX_OK) return rc;
+    size_t need[CB_COUNT];
+    chunk_sizes(pr, F, need);
+    for (int i = 0; i < CB_COUNT; ++i)
+        if (need[i] && (rc = ensure(c, *chunk_buf(sl, i), need[i])) != STX_OK) return rc;
     if ((size_t)F > sl.acc_host_cap) {
+        if (sl.gray.fixed) return fail(c, STX_ERR_NOMEM, "internal: result staging of the allocation-free path is too small");
         if (sl.acc_host) HIPCHK(c, hipHostFree(sl.acc_host));
         sl.acc_host = nullptr;
         sl.acc_host_cap = 0;
@@ -453,16 +511,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
     HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
-    if (lbp81) {
-        const double key[4] = {pr.off.rp[1], pr.off.rp[5], pr.off.cp[1], pr.off.cp[3]};
-        if (!c->tie.p || memcmp(key, c->tie_key, sizeof(key)) != 0) {
-            std::vector<uint8_t> blob;
-            build_tie_tables(pr.off, &blob, &c->tie_ncls);
-            if ((rc = ensure(c, c->tie, blob.size())) != STX_OK) return rc;
-            HIPCHK(c, hipMemcpy(c->tie.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
-            memcpy(c->tie_key, key, sizeof(key));
-        }
-    }
+    if (lbp81 && (rc = ensure_tie_tables(c, pr.off)) != STX_OK) return rc;
     // the second half of the tile flags doubles as "this tile holds a strong pixel" between the stencil and the first
     // hysteresis pass (the second pass is the first to write it as change flags)
     HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, s));
@@ -474,7 +523,6 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         sp.end();
     }
     if (!lbp81) {
-        if ((rc = ensure(c, sl.lpart, lbp_generic_part_bytes(g, F))) != STX_OK) return rc;
         Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 2, s);
         const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, (uint32_t*)sl.lpart.p, acc,
                                            opts.codes);
@@ -482,14 +530,11 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
     }
     if (p.quality_stats) {
-        if ((rc = ensure(c, sl.qpart, quality_part_bytes(g, F))) != STX_OK) return rc;
         Span sp(c, &sl.spans, STX_K_QUALITY, 2, s);
         launch_quality(s, (const uint8_t*)sl.gray.p, F, g, (unsigned long long*)sl.qpart.p, acc);
         sp.end();
     }
     if (pr.ext) {
-        if ((rc = ensure(c, sl.xpart, extended_part_bytes(g, F))) != STX_OK) return rc;
-        if ((rc = ensure(c, sl.lpart, lbp_generic_part_bytes(g, F))) != STX_OK) return rc;
         {
             Span sp(c, &sl.spans, STX_K_EXTENDED, 2, s);
             launch_extended(s, (const uint8_t*)sl.gray.p, F, g, p.canny_high, (unsigned long long*)sl.xpart.p, acc);
@@ -560,32 +605,53 @@ void finalize_extended(const FrameAcc& a, const Geom& g, stx_extended* x) {
 
 // Recomputes fft_sum / fft_sumsq of the listed frames of a finished chunk in double precision (the chunk's gray
 // planes are still in the slot).  One frame at a time: this is the path of rare, synthetic-looking frames.
-int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const std::vector<int>& frames) {
+int na_twiddles(stx_ctx* c, int which, int n);
+
+int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, int n_redo) {
     const Geom& g = pr.g;
     Fft64Work w;
     fft64_sizes(g, &w.spec_bytes, &w.scratch_bytes, &w.part_bytes);
     int rc;
-    if ((rc = ensure(c, c->spec64, w.spec_bytes)) != STX_OK) return rc;
-    if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes)) != STX_OK) return rc;
-    if ((rc = ensure(c, c->part64, w.part_bytes)) != STX_OK) return rc;
-    w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
     void *tw_w = nullptr, *tw_h = nullptr;
-    if ((rc = get_twiddles64(c, g.fw, &tw_w)) != STX_OK) return rc;
-    if ((rc = get_twiddles64(c, g.fh, &tw_h)) != STX_OK) return rc;
-    std::vector<double2> part((size_t)g.fwh);
-    for (int f : frames) {
+    double2* part_host;
+    if (sl.gray.fixed) {
+        // allocation-free path: the workspace was carved from the scratch array with the chunk's buffers, the
+        // twiddle tables have their own places in it, the column sums come back through the pinned staging
+        w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
+        if (c->spec64.cap < w.spec_bytes || c->scratch64.cap < w.scratch_bytes || c->part64.cap < w.part_bytes)
+            return fail(c, STX_ERR_NOMEM, "internal: fp64 workspace of the allocation-free path is too small");
+        if ((rc = na_twiddles(c, 2, g.fw)) != STX_OK || (rc = na_twiddles(c, 3, g.fh)) != STX_OK) return rc;
+        tw_w = c->na_base + NA_TW64_W;
+        tw_h = c->na_base + NA_TW64_H;
+        part_host = (double2*)c->na_stage;
+    } else {
+        if ((rc = ensure(c, c->spec64, w.spec_bytes)) != STX_OK) return rc;
+        if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes)) != STX_OK) return rc;
+        if ((rc = ensure(c, c->part64, w.part_bytes)) != STX_OK) return rc;
+        w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
+        if ((rc = get_twiddles64(c, g.fw, &tw_w)) != STX_OK) return rc;
+        if ((rc = get_twiddles64(c, g.fh, &tw_h)) != STX_OK) return rc;
+        try {
+            c->part64_host.resize((size_t)g.fwh);
+        } catch (const std::bad_alloc&) {
+            return fail(c, STX_ERR_NOMEM, "out of host memory");
+        }
+        part_host = c->part64_host.data();
+    }
+    for (int i = 0; i < n_redo; ++i) {
+        const int f = frames[i];
         launch_fft64(c->stream, (const uint8_t*)sl.gray.p + (size_t)f * g.grows * g.gpitch, g, pr.plan_w, pr.plan_h, tw_w,
                      tw_h, w);
-        HIPCHK(c, hipMemcpyAsync(part.data(), w.part, w.part_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(part_host, w.part, w.part_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         double s = 0.0, s2 = 0.0;  // fixed order: reproducible
-        for (int k = 0; k < g.fwh; ++k) { s += part[k].x; s2 += part[k].y; }
+        for (int k = 0; k < g.fwh; ++k) { s += part_host[k].x; s2 += part_host[k].y; }
         sl.acc_host[f].fft_sum = s;
         sl.acc_host[f].fft_sumsq = s2;
         sl.acc_host[f].pad0 = 1u;
     }
-    c->fft64_frames += frames.size();
+    c->fft64_frames += (uint64_t)n_redo;
     return STX_OK;
 }
 
@@ -609,11 +675,11 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx
         c->tacc.frames += (uint64_t)sl.F;
     }
     if (out && pr.p.fft_exact >= 0) {
-        std::vector<int> redo;
+        sl.redo.clear();  // (the allocation-free path's list is reserved at stx_create)
         for (int i = 0; i < sl.F; ++i)
-            if (pr.p.fft_exact > 0 || fft_needs_f64(sl.acc_host[i], pr.g)) redo.push_back(i);
-        if (!redo.empty()) {
-            const int rc = refine_fft64(c, sl, pr, redo);
+            if (pr.p.fft_exact > 0 || fft_needs_f64(sl.acc_host[i], pr.g)) sl.redo.push_back(i);
+        if (!sl.redo.empty()) {
+            const int rc = refine_fft64(c, sl, pr, sl.redo.data(), (int)sl.redo.size());
             if (rc != STX_OK) return rc;
         }
     }
@@ -708,6 +774,41 @@ int stx_create(int device_id, stx_ctx** out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].fft_done, hipEventDisableTiming);
     }
     if (e == hipSuccess) { step = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; e = fft_set_lds_limits(); }
+    // the allocation-free entry point: this GPU's copy of the scratch array, result and twiddle staging, events
+    if (e == hipSuccess) {
+        step = "hipGetSymbolAddress(scratch)";
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        c->na_base = (uint8_t*)p;
+    }
+    if (e == hipSuccess) {
+        step = "hipHostMalloc";
+        e = hipHostMalloc((void**)&c->na.acc_host, sizeof(FrameAcc) * (size_t)NA_MAX_CHUNK, hipHostMallocDefault);
+        if (e == hipSuccess) c->na.acc_host_cap = NA_MAX_CHUNK;
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->na.changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        *c->na.changed_host = 0;
+        e = hipHostMalloc(&c->na_stage, sizeof(double2) * (size_t)STX_MAX_DIM, hipHostMallocDefault);
+    }
+    if (e == hipSuccess) { step = "hipEventCreate"; e = hipEventCreateWithFlags(&c->na.done, hipEventDisableTiming); }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.gray_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.fft_done, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        try {
+            c->na.redo.reserve(NA_MAX_CHUNK);
+        } catch (const std::bad_alloc&) {
+            stx_destroy(c);
+            return STX_ERR_NOMEM;
+        }
+        // the flat-neighbourhood tables of the default LBP, so that no later call has to build them
+        LbpOffsets off;
+        if (lbp_offsets(8, 1.0, &off) != 0 || ensure_tie_tables(c, off) != STX_OK) {
+            g_create_err = c->err;
+            stx_destroy(c);
+            return STX_ERR_HIP;
+        }
+    }
     if (e != hipSuccess) {
         g_create_err = std::string(step) + ": " + hipGetErrorString(e);
         stx_destroy(c);
@@ -732,6 +833,17 @@ int stx_destroy(stx_ctx* c) {
         if (sl.fft_done) (void)hipEventDestroy(sl.fft_done);
         for (auto& t : sl.spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     }
+    if (c->na.acc_host) (void)hipHostFree(c->na.acc_host);
+    if (c->na.changed_host) (void)hipHostFree(c->na.changed_host);
+    if (c->na_stage) (void)hipHostFree(c->na_stage);
+    if (c->na.done) (void)hipEventDestroy(c->na.done);
+    if (c->na.gray_ready) (void)hipEventDestroy(c->na.gray_ready);
+    if (c->na.fft_done) (void)hipEventDestroy(c->na.fft_done);
+    for (auto& t : c->na.spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    // (the buffers of c->na and, after an allocation-free call, spec64 / scratch64 / part64 point into the scratch array)
+    if (c->spec64.fixed) c->spec64 = DevBuf();
+    if (c->scratch64.fixed) c->scratch64 = DevBuf();
+    if (c->part64.fixed) c->part64 = DevBuf();
     if (c->codes.p) (void)hipFree(c->codes.p);
     if (c->plane.p) (void)hipFree(c->plane.p);
     if (c->taps.p) (void)hipFree(c->taps.p);
@@ -767,6 +879,110 @@ int stx_analyze_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, i
     int rc = prepare(c, h, w, params, &pr);
     if (rc != STX_OK) return rc;
     return analyze_device_impl(c, bgr_dev, n_frames, row_stride, frame_stride, pr, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+// Twiddle table `which` (0: fp32 rows, 1: fp32 columns, 2: fp64 rows, 3: fp64 columns) of length n in its place in
+// the scratch array; uploaded through the pinned staging only when the length changes.
+int na_twiddles(stx_ctx* c, int which, int n) {
+    if (c->na_tw_n[which] == n) return STX_OK;
+    static const size_t off[4] = {NA_TW_W, NA_TW_H, NA_TW64_W, NA_TW64_H};
+    size_t bytes;
+    if (which < 2) {
+        float2* h = (float2*)c->na_stage;
+        for (int k = 0; k < n; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n;
+            h[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+        bytes = sizeof(float2) * (size_t)n;
+    } else {
+        double2* h = (double2*)c->na_stage;
+        for (int k = 0; k < n; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n;
+            h[k] = make_double2(cos(a), sin(a));
+        }
+        bytes = sizeof(double2) * (size_t)n;
+    }
+    c->na_tw_n[which] = 0;
+    HIPCHK(c, hipMemcpyAsync(c->na_base + off[which], c->na_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging is reused by the next table
+    c->na_tw_n[which] = n;
+    return STX_OK;
+}
+
+// Points the buffers of the allocation-free slot (and the fp64 workspace) at pieces of the scratch array for a chunk
+// of F frames; returns the bytes used, or 0 if they do not fit.
+size_t na_carve(stx_ctx* c, const Prepared& pr, int F) {
+    size_t need[CB_COUNT];
+    chunk_sizes(pr, F, need);
+    size_t at = NA_BUFFERS;
+    auto take = [&](DevBuf& b, size_t bytes) {
+        b.p = bytes ? c->na_base + at : nullptr;
+        b.cap = bytes;
+        b.fixed = true;
+        at += (bytes + 255) & ~(size_t)255;
+    };
+    for (int i = 0; i < CB_COUNT; ++i) take(*chunk_buf(c->na, i), need[i]);
+    if (pr.p.fft_exact >= 0) {
+        size_t sb, cb, pb;
+        fft64_sizes(pr.g, &sb, &cb, &pb);
+        take(c->spec64, sb);
+        take(c->scratch64, cb);
+        take(c->part64, pb);
+    }
+    return at <= (size_t)STX_NOALLOC_SCRATCH_BYTES ? at : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stx_analyze_batch_device_noalloc(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                     int64_t frame_stride, const stx_params* params, stx_metrics* out) {
+    if (!c) return STX_ERR_INVALID;
+    if (n_frames < 0) return fail(c, STX_ERR_INVALID, "n_frames < 0");
+    if (n_frames == 0) return STX_OK;
+    if (!bgr_dev || !out) return fail(c, STX_ERR_INVALID, "null pointer");
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
+        return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
+    if (any_busy(c)) return fail(c, STX_ERR_INVALID, "asynchronous submissions are outstanding: call stx_wait first");
+    if (c->timing) return fail(c, STX_ERR_INVALID, "switch kernel timing off for the allocation-free entry point");
+    if (params && params->quality_stats) return fail(c, STX_ERR_UNSUPPORTED, "quality_stats is not available on the allocation-free entry point");
+    Prepared pr;
+    int rc = prepare(c, h, w, params, &pr, false);
+    if (rc != STX_OK) return rc;
+    if (!(pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0))
+        return fail(c, STX_ERR_UNSUPPORTED, "the allocation-free entry point computes LBP at (P=8, R=1) only");
+    // the fp64 workspace of spec64 / scratch64 / part64 may belong to the allocating entry points: park it
+    DevBuf keep[3] = {c->spec64, c->scratch64, c->part64};
+    auto restore = [&]() {
+        if (!keep[0].fixed) c->spec64 = keep[0]; else c->spec64 = DevBuf();
+        if (!keep[1].fixed) c->scratch64 = keep[1]; else c->scratch64 = DevBuf();
+        if (!keep[2].fixed) c->part64 = keep[2]; else c->part64 = DevBuf();
+    };
+    int chunk = std::min(n_frames, NA_MAX_CHUNK);
+    while (chunk >= 1 && na_carve(c, pr, chunk) == 0) chunk = chunk > 8 ? chunk - chunk / 8 : chunk - 1;
+    if (chunk < 1) {
+        restore();
+        return fail(c, STX_ERR_UNSUPPORTED, "frame too large for the static scratch array of the allocation-free entry point "
+                                          "(gray plane, edge maps, half spectrum and, unless fft_exact is -1, one fp64 "
+                                          "spectrum must fit 128 MiB)");
+    }
+    if ((rc = na_twiddles(c, 0, pr.g.fw)) == STX_OK) rc = na_twiddles(c, 1, pr.g.fh);
+    pr.tw_w = (float2*)(c->na_base + NA_TW_W);
+    pr.tw_h = (float2*)(c->na_base + NA_TW_H);
+    for (int f0 = 0; f0 < n_frames && rc == STX_OK; f0 += chunk) {
+        const int F = std::min(chunk, n_frames - f0);
+        ChunkOpts o;
+        rc = enqueue_chunk(c, c->na, bgr_dev + (int64_t)f0 * frame_stride, row_stride, frame_stride, F, pr, o);
+        if (rc == STX_OK) rc = finish_chunk(c, c->na, pr, out + f0);
+    }
+    if (rc != STX_OK) sync_all(c);
+    restore();
+    return rc;
 }
 
 int stx_analyze_extended_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
