@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE; they do not fit in
-one pass) over scratch/prof1.py, which analyses FRAMES 1080p frames per dispatch.
+one pass) over tools/prof1.py, which analyses FRAMES 1080p frames per dispatch.
 
     python profiles/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames> <out.json>
 

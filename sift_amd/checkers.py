@@ -33,8 +33,10 @@ def _quality_records(detector: TextureNoiseDetector, frames: Sequence[np.ndarray
     """One record per frame with the quality fields filled; None where the frame cannot be analysed
     (the reference catches per-frame errors and substitutes a default score)."""
     ctx = detector._ctx
-    params = ctx.default_params() if detector._params is None else detector._params
-    saved = params.quality_stats
+    # a private copy of the detector's parameters: the detector (and anyone holding its struct) never sees the change
+    params = ctx.default_params()
+    if detector._params is not None:
+        C.memmove(C.byref(params), C.byref(detector._params), C.sizeof(params))
     params.quality_stats = 1
     out: List[Optional[StxMetrics]] = [None] * len(frames)
     groups: Dict[tuple, List[int]] = {}
@@ -48,15 +50,12 @@ def _quality_records(detector: TextureNoiseDetector, frames: Sequence[np.ndarray
             continue
         arrs.append(a)
         groups.setdefault(a.shape, []).append(i)
-    try:
-        for idxs in groups.values():
-            res = ctx.analyze_frames([arrs[i] for i in idxs], params)
-            for j, i in enumerate(idxs):
-                r = StxMetrics()
-                C.memmove(C.byref(r), C.byref(res[j]), C.sizeof(StxMetrics))
-                out[i] = r
-    finally:
-        params.quality_stats = saved
+    for idxs in groups.values():
+        res = ctx.analyze_frames([arrs[i] for i in idxs], params)
+        for j, i in enumerate(idxs):
+            r = StxMetrics()
+            C.memmove(C.byref(r), C.byref(res[j]), C.sizeof(StxMetrics))
+            out[i] = r
     return out
 
 

@@ -180,13 +180,7 @@ FftLayout fft_choose_layout(const Geom& g) {
     l.fast_cols = fft_fast_available(g.fh);
     int cbw;
     if (l.fast_cols) {
-        const int stride = fft_fast_stride(g.fh);
-        // two workgroups per CU (each at most half of the LDS), so that one can load its block while
-        // the other computes
-        cbw = 16;
-        while (cbw > 1 && (size_t)cbw * stride * sizeof(float2) > (size_t)FFT_LDS_MAX / 2) cbw >>= 1;
-        const int tpw = fft_fast_tpw(g.fh);
-        if (cbw < tpw) cbw = tpw;
+        cbw = fft_fast_cbw(g.fh);
     } else {
         cbw = FFT_LDS_MAX / (2 * g.fh * (int)sizeof(float2));
         if (cbw > 8) cbw = 8;

@@ -227,6 +227,15 @@ struct Plan {
     static constexpr int TPW = 64 / LPT_;          // transforms per wave
     static constexpr int S = N_ | 1;               // LDS elements per transform (odd: see cols_kernel)
     static constexpr bool SWZ = (N_ & (N_ - 1)) == 0;
+    // Columns per workgroup of the column kernel: as many as fit half of the CU's LDS (two workgroups per CU, so
+    // that one loads its block while the other computes), a power of two, at most 16, at least one wave's worth.
+    static constexpr int cbw_fit() {
+        int c = 16;
+        while (c > 1 && (long)c * S * 8 > (159 * 1024) / 2) c >>= 1;
+        return c < TPW ? TPW : c;
+    }
+    static constexpr int CBW = cbw_fit();
+    static constexpr int COLS_THREADS = 64 * CBW / TPW;
     static_assert(SWZ || (R0_ & 1), "sizes with an odd factor must start with an odd radix");
 };
 
@@ -724,7 +733,7 @@ struct ColsDirect {
 
 // blockDim.x = 64 * cbw / TPW ; dynamic LDS = cbw * S float2
 template <class P>
-__global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
+__global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     extern __shared__ float2 dynlds[];
     constexpr int N = P::N, LPT = P::LPT, S = P::S;
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -865,7 +874,11 @@ __global__ __launch_bounds__(1024) void cols_kernel(ColsArgs a) {
     X(1280, 5, 16, 16, 1, 64)  \
     X(1440, 9, 16, 10, 1, 64)  \
     X(1920, 15, 16, 8, 1, 64)  \
-    X(2048, 16, 16, 8, 1, 64)
+    X(2048, 16, 16, 8, 1, 64)  \
+    X(2160, 9, 15, 16, 1, 64)  \
+    X(2560, 5, 16, 16, 2, 64)  \
+    X(3840, 15, 16, 16, 1, 64) \
+    X(4096, 16, 16, 16, 1, 64)
 
 template <class P>
 void launch_rows_t(hipStream_t s, RowsArgs a, int n_frames) {
@@ -922,24 +935,12 @@ bool fft_fast_available(int n) {
     }
 }
 
-// LDS elements per transform of the fast column kernel (0 if the size has no fast kernel)
-int fft_fast_stride(int n) {
+// columns per workgroup of the fast column kernel (0 if the size has no fast kernel)
+int fft_fast_cbw(int n) {
     switch (n) {
 #define X(N, A, B, C, D, L) \
     case N:                 \
-        return Plan<N, A, B, C, D, L>::S;
-        STX_FFT_SIZES(X)
-#undef X
-        default:
-            return 0;
-    }
-}
-
-int fft_fast_tpw(int n) {
-    switch (n) {
-#define X(N, A, B, C, D, L) \
-    case N:                 \
-        return Plan<N, A, B, C, D, L>::TPW;
+        return Plan<N, A, B, C, D, L>::CBW;
         STX_FFT_SIZES(X)
 #undef X
         default:

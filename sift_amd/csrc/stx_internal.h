@@ -144,8 +144,7 @@ void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const
 hipError_t fft64_set_lds_limits();
 // compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
 bool fft_fast_available(int n);
-int fft_fast_stride(int n);
-int fft_fast_tpw(int n);
+int fft_fast_cbw(int n);
 hipError_t fft_fast_init();
 bool launch_fft_rows_fast(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                           const float2* tw, float2* spec);

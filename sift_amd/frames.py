@@ -25,6 +25,30 @@ from .texture import TextureContext
 MAX_SERVICE_FRAMES = 450  # main.py:393
 
 
+class _PinnedPages:
+    """Owner of one page-locked allocation, exported through the buffer protocol: numpy arrays built on it keep
+    it (and through it the context) alive, and the memory goes back to the library when the last one dies."""
+
+    def __init__(self, ctx: TextureContext, nbytes: int):
+        self.ctx = ctx
+        p = C.c_void_p()
+        ctx._check(ctx.lib.stx_pinned_alloc(ctx.handle, nbytes, C.byref(p)), "stx_pinned_alloc")
+        self._ptr = p
+        self._buf = (C.c_uint8 * nbytes).from_address(p.value)
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (len(self._buf),), "typestr": "|u1", "data": (self._ptr.value, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self._ptr and self.ctx.handle:
+                self.ctx.lib.stx_pinned_free(self.ctx.handle, self._ptr)
+            self._ptr = None
+        except Exception:
+            pass
+
+
 class PinnedFrameBatch:
     """A reusable page-locked frame buffer in the ``extract_frames`` layout."""
 
@@ -34,24 +58,16 @@ class PinnedFrameBatch:
         self.ctx = ctx
         self.capacity, self.height, self.width = int(capacity), int(height), int(width)
         self.nbytes = self.capacity * self.height * self.width * 3
-        p = C.c_void_p()
-        ctx._check(ctx.lib.stx_pinned_alloc(ctx.handle, self.nbytes, C.byref(p)), "stx_pinned_alloc")
-        self._ptr = p
-        buf = (C.c_uint8 * self.nbytes).from_address(p.value)
-        self.array = np.frombuffer(buf, dtype=np.uint8).reshape(self.capacity, self.height, self.width, 3)
+        self._pages = _PinnedPages(ctx, self.nbytes)
+        # every numpy view handed out (array, frames()) has the pages object as its base, so the page-locked
+        # memory is released only after the batch AND the last such view are gone
+        self.array = np.asarray(self._pages).reshape(self.capacity, self.height, self.width, 3)
         self.count = 0  # frames currently held
 
     def close(self):
-        if getattr(self, "_ptr", None) is not None and self._ptr:
-            self.array = None
-            self.ctx.lib.stx_pinned_free(self.ctx.handle, self._ptr)
-            self._ptr = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """Drop the batch's own references; the pages are freed when no view of them is left."""
+        self.array = None
+        self._pages = None
 
     # ---- filling
     def clear(self):

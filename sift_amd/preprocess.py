@@ -26,8 +26,16 @@ class FramePreprocessor:
         """[N][3][H][W] float32 on the GPU from N same-shaped BGR frames."""
         frames = [TextureNoiseDetector._as_frame(f) for f in frames]
         w, h = self.input_size
-        out = self._ctx.preprocess_frames(frames, out_h=h, out_w=w)
-        return torch.from_numpy(out).to(self.device)
+        out = torch.empty((len(frames), 3, h, w), dtype=torch.float32, device=self.device)
+        if not frames:
+            return out
+        if len({f.shape for f in frames}) != 1:
+            raise ValueError("all frames of one call must have the same shape")
+        # frames go up once, the kernel writes the network's input tensor in place: nothing comes back to the host
+        src = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.device)
+        fh, fw = frames[0].shape[:2]
+        self._ctx.preprocess_device(src.data_ptr(), len(frames), fh, fw, out.data_ptr(), out_h=h, out_w=w)
+        return out
 
     def _preprocess_frame(self, frame: np.ndarray) -> torch.Tensor:
         return self.preprocess_frames([frame])

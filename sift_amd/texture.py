@@ -62,23 +62,20 @@ class TextureContext:
         if ch != 3:
             raise ValueError("frames must be H x W x 3 (BGR)")
         keep = []
-        ptrs = (C.c_void_p * n)()
-        stride = None
-        for i, f in enumerate(frames):
+        for f in frames:
             if f.shape != (h, w, 3):
                 raise ValueError("all frames of one call must have the same shape")
-            if f.dtype != np.uint8 or f.strides[2] != 1 or f.strides[1] != 3 or f.strides[0] < 3 * w or (
-                    stride is not None and f.strides[0] != stride):
+            if f.dtype != np.uint8 or f.strides[2] != 1 or f.strides[1] != 3 or f.strides[0] < 3 * w:
                 f = np.ascontiguousarray(f, dtype=np.uint8)
-            if stride is None:
-                stride = f.strides[0]
-            if f.strides[0] != stride:
-                f = np.ascontiguousarray(f, dtype=np.uint8)
-                if f.strides[0] != stride:
-                    raise ValueError("frames with different row strides in one call")
             keep.append(f)
+        # the call takes one row stride: views with padded rows pass as they are when all of them agree, any
+        # mix of strides (a crop view beside a contiguous frame) is made contiguous first
+        if len({f.strides[0] for f in keep}) > 1:
+            keep = [np.ascontiguousarray(f) for f in keep]
+        ptrs = (C.c_void_p * n)()
+        for i, f in enumerate(keep):
             ptrs[i] = f.ctypes.data
-        return keep, ptrs, h, w, stride
+        return keep, ptrs, h, w, keep[0].strides[0]
 
     # ---- host frames
     def analyze_frames(self, frames: Sequence[np.ndarray], params: Optional[StxParams] = None):

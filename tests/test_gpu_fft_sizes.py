@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FAST_SIZES = [64, 80, 96, 128, 160, 240, 256, 320, 360, 480, 512, 540, 640, 720, 768, 960, 1024, 1080, 1280, 1440,
-              1920, 2048]
+              1920, 2048, 2160, 2560, 3840, 4096]
 
 
 @pytest.fixture(scope="module")
@@ -31,3 +31,13 @@ def test_fast_fft_length(ctx, n):
         r = ctx.analyze_frames([bgr, bgr[::-1].copy()])
         assert r[0].frequency_anomaly == pytest.approx(_ref(g), rel=1e-5), (h, w)
         assert r[1].frequency_anomaly == pytest.approx(_ref(g[::-1]), rel=1e-5), (h, w)
+
+
+def test_4k_full_frame_transform(ctx):
+    """The default call on a 4K frame transforms the whole frame (passive_checker.py:120): 2160 x 3840."""
+    from sift_amd.synth import synth_frame
+    f = synth_frame("natural", 0x5EED0004, 1, 0, 2160, 3840)
+    r = ctx.analyze_frames([f])[0]
+    # the gray plane as the library computes it, through the debug entry point, then numpy's complex128 transform
+    gray, _, _ = ctx.debug_planes(f)
+    assert r.frequency_anomaly == pytest.approx(_ref(gray), rel=1e-5)

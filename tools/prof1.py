@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 import torch
 from sift_amd.texture import TextureContext
 from sift_amd._lib import StxMetrics
