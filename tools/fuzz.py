@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, 'tests/golden')
 import numpy as np
 from oracle import texture_oracle as O
 from sift_amd.texture import TextureContext

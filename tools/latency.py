@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sift_amd.texture import TextureNoiseDetector
 from sift_amd.synth import synth_frame

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sift_amd.texture import TextureContext
 from sift_amd._lib import StxMetrics
