@@ -13,15 +13,24 @@
 // The Canny bits of a pixel column are collected down the strip (one 32-bit word per column
 // and strip), which is the layout the hysteresis kernel works on: [frame][64-row word][column].
 //
-// LBP: the four axis samples are the neighbouring pixels themselves; the four diagonal samples
-// are bilinear.  Their sign against the centre is first decided in 16.16 fixed point (two
-// v_dot2_u32_u16 per sample); the rounded weights put that value within about 140/65536 of the exact
-// one (the bound is computed from the actual rounding errors at launch), so anything further
-// than that from the centre has the sign scikit-image's fp64 arithmetic produces.  Pixels with a
-// closer sample (exact ties, mostly: about 3 % of the pixels of a low-contrast image) go through a
-// wave-wide queue in LDS and are re-evaluated in the order-exact fp64 sequence by whichever lane is
-// free, so the slow path costs ceil(queued / 64) rounds per block of rows instead of the worst lane's
-// count.  This file must be compiled with -ffp-contract=off.
+// LBP: the four axis samples are the neighbouring pixels themselves; the four diagonal samples are bilinear.
+// skimage rounds the sample offsets to five decimals, so a diagonal sample sits at (+-0.70711, +-0.70711) and, the
+// bilinear weights adding up to one,
+//     sample - centre = 0.70711e-5 * ( 70711 * (D - c) + 29289 * ((A - c) + (B - c)) )
+// with D the diagonal neighbour and A, B the two axis neighbours of that quadrant: an integer N decides the sign, and
+// N = 0 needs D = c and A + B = 2c (70711 and 29289 are coprime).  29/70 is a continued-fraction convergent of
+// 29289/70711: N' = 70 (D - c) + 29 (A + B - 2c) fits 16 bits and is off from 70 N / 70711 by at most
+// 0.00536 * 510 < 2.74, so |N'| >= 3 has the sign of N -- which is at least 263 in magnitude then, a sample 1.9e-3
+// gray levels from the centre, far outside anything fp64 rounding does.  N' in [-2, 2] (exact ties, mostly: about 3 %
+// of the pixels of a low-contrast image) goes through a wave-wide queue in LDS and is re-evaluated in the order-exact
+// fp64 sequence by whichever lane is free, so the slow path costs ceil(queued / 64) rounds per block of rows instead
+// of the worst lane's count.  This file must be compiled with -ffp-contract=off.
+//
+// Instruction choice: on gfx950 a plain 32-bit add / sub / and / or / xor / right shift whose operands are vector
+// registers or literals issues in about half the time of any packed, three-operand, permute or compare instruction.
+// Both pixels of a lane live in the 16-bit halves of one register, so wherever a half cannot carry or borrow into
+// the other (sums of small non-negative values; a - b with bit 15 of a set and b < 2^15) the code uses the plain
+// instruction on the whole word.  A comparison a >= b is bit 15 of (a | 0x8000) - b.
 #include <utility>
 #include <vector>
 
@@ -58,6 +67,8 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t c) {  // a*K + c
     asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "n"(K), "v"(c));
     return d;
 }
+// a*k + c per half with the multiplier in a register (constants above 64 cannot be inline operands)
+__device__ __forceinline__ uint32_t pk_mad_r(uint32_t a, uint32_t k, uint32_t c) { return word(asU(a) * asU(k) + asU(c)); }
 template <int K>
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a) {
     const us2 k = {(unsigned short)K, (unsigned short)K};
@@ -132,9 +143,6 @@ struct StencilArgs {
     int H, W, gpitch, grows, bm_words;
     uint32_t low2, high2;                   // thresholds, clamped to [-1, 4095], in both halves
     double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
-    // 16.16 weights of the diagonal samples 1,3,5,7: (left, right) pixel of the upper and lower cell row
-    uint32_t w1t, w1b, w3t, w3b, w5t, w5b, w7t, w7b;
-    uint32_t margin;   // bound on |fixed-point sample - exact sample| in 1/65536 gray levels, plus a guard
     uint32_t* part;    // [frame][tiles][16]: 10 LBP bins, hp sum, hp sum of squares, |gray-blur| sum, gray sum
     uint32_t* strong;  // [frame][bm_words][W] 64-bit words, written as 32-bit halves (one per 32-row strip)
     uint32_t* cand;
@@ -146,7 +154,7 @@ struct StencilArgs {
     //   [0, TIE_COORDS)              row y    -> class of the row's two fractional offsets
     //   [TIE_COORDS, 2*TIE_COORDS)   column x -> class of the column's two fractional offsets
     //   [2*TIE_COORDS]               number of column classes
-    //   [TIE_LUT_OFF ...)            [row class][column class][gray level] -> nibble in the layout of sgd_lo/sgd_hi
+    //   [TIE_LUT_OFF ...)            [row class][column class][gray level] -> LBP bits of samples 1,3,5,7 (bit 3 .. 0)
     const uint8_t* tie;
     // [frame][ceil(W/64)][bm_words] bytes, zeroed by the caller: set to 1 for every 64x64 hysteresis tile that
     // holds a strong pixel (the first hysteresis pass skips tiles with none in or around them unseen)
@@ -154,6 +162,11 @@ struct StencilArgs {
     int bm_tiles;
 };
 constexpr int TIE_LUT_OFF = 2 * TIE_COORDS + 256;
+constexpr uint32_t HH = 0x80008000u;  // bit 15 of both halves
+// A pixel's eight LBP bits (1 = sample >= centre) sit at bits 10..3 of its half, which makes the half the byte
+// offset of its entry in the histogram table: samples 1,3,5,7 at bits 10..7, samples 0,2,4,6 at bits 6..3.
+constexpr int DIAG_SHIFT = 7;
+constexpr uint32_t TIE_BAND = 0x00050005u;  // N' + 2 in [0, 5) is undecided
 
 // byte selectors for v_perm_b32 over {hi source, lo source}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = zero
 constexpr uint32_t SEL_PAIR = 0x0c010c00;   // (b0, b1) of the low source
@@ -163,13 +176,20 @@ constexpr uint32_t SEL_CROSS = 0x0c040c01;  // (b1 of the low source, b0 of the 
 struct RowD {
     uint32_t hg;            // horizontal [1 4 6 4 1] (reflected border)
     uint32_t rs;            // horizontal 3-sum (reflected border)
-    uint32_t zm1, z0, zp1;  // pixel pairs (x-1,x) (x,x+1) (x+1,x+2), zero outside the image (LBP view)
+    uint32_t z0;            // the pixel pair (x,x+1), zero outside the image (LBP view)
+    // LBP view (zero outside the image), bit 15 of each half set: pairs (x,x+1) (x-1,x) (x+1,x+2)
+    uint32_t zh0, zhm, zhp;
+    // linear parts of the diagonal samples: with rows r-1, r, r+1 and the pairs m = (x-1,x), p = (x+1,x+2),
+    //   rp = 70 p + 29 z0, rm = 70 m + 29 z0      (contribution of a row above / below the centre row)
+    //   gp = 29 p - 128 z0 + 0x8002, gm likewise    (contribution of the centre row itself)
+    // so that rp[r-1] + gp[r] = 0x8000 + 2 + N' of sample 1 and so on; every half stays inside [0x82, 0xff82].
+    uint32_t rp, rm, gp, gm;
     uint32_t d, sm;         // horizontal Sobel difference and smoothing (replicated border, Canny view)
 };
 
 template <bool BORDER, bool DO_LBP, bool CODES>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const uint2* lut,
-                                      uint16_t* wq /*[QUEUE_ITEMS] per wave*/, uint32_t* wsg /*[128] per wave*/,
+                                      uint16_t* wq /*[QUEUE_ITEMS / 4] per wave*/, uint32_t* park /*[BLOCK_ROWS][64] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
     const int x = x0 + 2 * lane;  // this lane's pixels: x (low half) and x+1 (high half)
@@ -224,20 +244,21 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         const uint32_t A = p[0], B = p[1], C = p[2];  // bytes (x-2,x-1) (x,x+1) (x+2,x+3)
         const uint32_t tm2 = perm(0, A, SEL_PAIR), tm1 = perm(B, A, SEL_CROSS), t0 = perm(0, B, SEL_PAIR),
                        tp1 = perm(C, B, SEL_CROSS), tp2 = perm(0, C, SEL_PAIR);
-        const uint32_t s1 = pk_add(tm1, tp1);
-        o.hg = pk_mad<6>(t0, pk_mad<4>(s1, pk_add(tm2, tp2)));
-        o.rs = pk_add(s1, t0);
+        const uint32_t s1 = tm1 + tp1;  // halves of at most 510: plain adds
+        o.hg = pk_mad<6>(t0, pk_mad<4>(s1, tm2 + tp2));
+        o.rs = s1 + t0;
+        uint32_t zm1, zp1;
         if (!BORDER) {
-            o.zm1 = tm1; o.z0 = t0; o.zp1 = tp1;
+            zm1 = tm1; o.z0 = t0; zp1 = tp1;
             o.d = pk_sub(tp1, tm1);
             o.sm = pk_mad<2>(t0, s1);
         } else {
             const int ry = ys - 2 + rel;
             const bool rin = ry >= 0 && ry < H;
             const uint32_t AB = A | (B << 16);
-            o.zm1 = rin ? perm(C, AB, selZ[0]) : 0u;
+            zm1 = rin ? perm(C, AB, selZ[0]) : 0u;
             o.z0 = rin ? perm(C, AB, selZ[1]) : 0u;
-            o.zp1 = rin ? perm(C, AB, selZ[2]) : 0u;
+            zp1 = rin ? perm(C, AB, selZ[2]) : 0u;
             uint32_t cAB = AB, cC = C;
             if (!rin) {  // wave-uniform: the Canny view repeats the first / last image row
                 const uint16_t* q = reinterpret_cast<const uint16_t*>(tile + (iclamp(ry, 0, H - 1) - y0 + 2) * LPITCH +
@@ -247,7 +268,18 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             }
             const uint32_t cm1 = perm(cC, cAB, selC[0]), c0 = perm(cC, cAB, selC[1]), cp1 = perm(cC, cAB, selC[2]);
             o.d = pk_sub(cp1, cm1);
-            o.sm = pk_mad<2>(c0, pk_add(cm1, cp1));
+            o.sm = pk_mad<2>(c0, cm1 + cp1);
+        }
+        if (DO_LBP) {
+            const uint32_t q0 = pk_mul<29>(o.z0);
+            o.rp = pk_mad_r(zp1, 0x00460046u, q0);  // 70
+            o.rm = pk_mad_r(zm1, 0x00460046u, q0);
+            const uint32_t e = pk_mad_r(o.z0, 0xFF80FF80u, 0x80028002u);  // 0x8002 - 128 c per half
+            o.gp = pk_mad<29>(zp1, e);
+            o.gm = pk_mad<29>(zm1, e);
+            o.zh0 = o.z0 | HH;
+            o.zhm = zm1 | HH;
+            o.zhp = zp1 | HH;
         }
     };
 
@@ -260,7 +292,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         o.ax = pk_abs(gx);
         o.ay = pk_abs(gy);
         o.sxy = gx ^ gy;
-        uint32_t m = pk_add(o.ax, o.ay);
+        uint32_t m = o.ax + o.ay;  // at most 2040 per half
         if (BORDER) m &= (r >= 0 && r < H) ? vm : 0u;
         const int rel = r - (ys - 1);
         const int hl = __builtin_amdgcn_readlane(haloL16, rel);
@@ -300,10 +332,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             accC = pk_mul<256>(accC);
         } else {
             const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
-            // LBP state of this block.  Signs are stored as "1 = sample below the centre".
-            uint32_t sgA[BLOCK_ROWS];         // axis samples 0,2,4,6 at bits 15..12 / 31..28 (two pixels)
-            uint32_t sgd_lo = 0, sgd_hi = 0;  // diagonal samples 1,3,5,7: one nibble per row, row 0 highest
-            uint32_t pend = 0;                // near-tie flags, pushed low pixel then high pixel per row
+            // LBP state of this block: the bit words of the rows go to LDS (park[row][lane]) as they are made, where
+            // the second stage can patch them; pend holds the undecided flags, row i at bit 15-i (low pixel) and
+            // 31-i (high pixel).
+            uint32_t pend = 0;
 #pragma unroll
             for (int i = 0; i < BLOCK_ROWS; ++i) {
                 const int y = yb + i;
@@ -314,7 +346,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 
                 // ---- high-pass: 8c - sum(neighbours) = 9c - sum(3x3), saturated to u8
                 {
-                    const uint32_t sum3 = pk_add(pk_add(rw[1].rs, rw[2].rs), rw[3].rs);
+                    const uint32_t sum3 = rw[1].rs + rw[2].rs + rw[3].rs;  // at most 2295 per half
                     const uint32_t v = pk_min(pk_sub_sat(pk_mul<9>(c2), sum3), 0x00FF00FFu);
                     hp_s = sad_u16(v, 0, hp_s);
                     hp_q = dot2(v, v, hp_q);
@@ -322,47 +354,31 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 }
                 // ---- Gaussian residual
                 {
-                    const uint32_t S = pk_mad<6>(rw[2].hg, pk_mad<4>(pk_add(rw[1].hg, rw[3].hg), pk_add(rw[0].hg, rw[4].hg)));
-                    uint32_t blur = pk_shr<8>(pk_add(S, 0x00800080u));
+                    const uint32_t S = pk_mad<6>(rw[2].hg, pk_mad<4>(rw[1].hg + rw[3].hg, rw[0].hg + rw[4].hg));
+                    uint32_t blur = pk_shr<8>(S + 0x00800080u);  // S is at most 255 * 256 per half
                     if (BORDER) blur &= vmy;
                     ad_s = sad_u16(c2, blur, ad_s);
                 }
-                // ---- LBP (P=8, R=1), first stage
+                // ---- LBP (P=8, R=1), first stage: bit 15 of each half of a difference is "sample >= centre"
                 if (DO_LBP) {
-                    // axis samples: the neighbours themselves, both pixels at once
-                    const uint32_t r0 = pk_sub(rw[2].zp1, c2);  // sample 0 (0,+1)
-                    const uint32_t r2 = pk_sub(rw[1].z0, c2);   // sample 2 (-1,0)
-                    const uint32_t r4 = pk_sub(rw[2].zm1, c2);  // sample 4 (0,-1)
-                    const uint32_t r6 = pk_sub(rw[3].z0, c2);   // sample 6 (+1,0)
-                    sgA[i] = bfi(0x80008000u, r0, bfi(0x40004000u, r2 >> 1, bfi(0x20002000u, r4 >> 2, r6 >> 3)));
-                    // diagonal samples in 16.16 fixed point, offset by the margin: t = (sample - centre) + margin.
-                    // t < 0 or t > 2*margin settles the sign (and then sign(t) is the sign); otherwise queue.
-                    const uint32_t lim1 = 2 * a.margin + 1;  // t <= 2*margin  <=>  t - lim1 < 0
-                    const uint32_t init_lo = a.margin - (c2 << 16);
-                    const uint32_t init_hi = a.margin - (c2 & 0xFFFF0000u);
-                    uint32_t tmin;
-                    {
-                        const uint32_t t1 = dot2(rw[1].z0, a.w1t, dot2(rw[2].z0, a.w1b, init_lo));    // (-.7,+.7)
-                        const uint32_t t3 = dot2(rw[1].zm1, a.w3t, dot2(rw[2].zm1, a.w3b, init_lo));  // (-.7,-.7)
-                        const uint32_t t5 = dot2(rw[2].zm1, a.w5t, dot2(rw[3].zm1, a.w5b, init_lo));  // (+.7,-.7)
-                        const uint32_t t7 = dot2(rw[2].z0, a.w7t, dot2(rw[3].z0, a.w7b, init_lo));    // (+.7,+.7)
-                        sgd_lo = push_sign(push_sign(push_sign(push_sign(sgd_lo, t1), t3), t5), t7);
-                        // samples below the centre wrap to huge values: the unsigned minimum is the smallest
-                        // t >= 0 (capped at 2^31 - 1 so that the subtraction's sign bit is the flag)
-                        tmin = min(min(min(t1, t3), t5), min(t7, 0x7FFFFFFFu));
-                        if (BORDER) tmin = (vmy & 0xFFFFu) ? tmin : 0x7FFFFFFFu;
-                        pend = push_sign(pend, tmin - lim1);
-                    }
-                    {
-                        const uint32_t t1 = dot2(rw[1].zp1, a.w1t, dot2(rw[2].zp1, a.w1b, init_hi));
-                        const uint32_t t3 = dot2(rw[1].z0, a.w3t, dot2(rw[2].z0, a.w3b, init_hi));
-                        const uint32_t t5 = dot2(rw[2].z0, a.w5t, dot2(rw[3].z0, a.w5b, init_hi));
-                        const uint32_t t7 = dot2(rw[2].zp1, a.w7t, dot2(rw[3].zp1, a.w7b, init_hi));
-                        sgd_hi = push_sign(push_sign(push_sign(push_sign(sgd_hi, t1), t3), t5), t7);
-                        tmin = min(min(min(t1, t3), t5), min(t7, 0x7FFFFFFFu));
-                        if (BORDER) tmin = (vmy >> 16) ? tmin : 0x7FFFFFFFu;
-                        pend = push_sign(pend, tmin - lim1);
-                    }
+                    const uint32_t a0 = rw[2].zhp - c2;  // sample 0 (0,+1)
+                    const uint32_t a2 = rw[1].zh0 - c2;  // sample 2 (-1,0)
+                    const uint32_t a4 = rw[2].zhm - c2;  // sample 4 (0,-1)
+                    const uint32_t a6 = rw[3].zh0 - c2;  // sample 6 (+1,0)
+                    const uint32_t f1 = rw[1].rp + rw[2].gp;  // (-.7,+.7): 0x8002 + N'
+                    const uint32_t f3 = rw[1].rm + rw[2].gm;  // (-.7,-.7)
+                    const uint32_t f5 = rw[3].rm + rw[2].gm;  // (+.7,-.7)
+                    const uint32_t f7 = rw[3].rp + rw[2].gp;  // (+.7,+.7)
+                    const uint32_t bits = ((f1 >> 5) & 0x04000400u) | ((f3 >> 6) & 0x02000200u) |
+                                          ((f5 >> 7) & 0x01000100u) | ((f7 >> 8) & 0x00800080u) |
+                                          ((a0 >> 9) & 0x00400040u) | ((a2 >> 10) & 0x00200020u) |
+                                          ((a4 >> 11) & 0x00100010u) | ((a6 >> 12) & 0x00080008u);
+                    park[i * 64 + lane] = bits;
+                    // undecided: 0x8000 <= f < 0x8005, i.e. subtracting 5 clears bit 15 (f is at least 0x82)
+                    uint32_t und = (f1 ^ (f1 - TIE_BAND)) | (f3 ^ (f3 - TIE_BAND)) | (f5 ^ (f5 - TIE_BAND)) |
+                                   (f7 ^ (f7 - TIE_BAND));
+                    if (BORDER) und &= vmy;
+                    pend |= (und & HH) >> i;
                 }
                 // ---- Canny non-maximum suppression + double threshold on both pixels at once.  The sign
                 // bit of each 16-bit difference is the predicate; masks select the two neighbours along the
@@ -400,17 +416,18 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 mg[1] = mg[2];
             }
             if (DO_LBP) {
-                // ---- LBP second stage.  Every lane appends its queued pixels to the wave's queue (positions from
-                // a prefix sum of the counts) and parks its diagonal nibbles in LDS; then lane l takes queue entry
-                // l, l+64, ...: all four diagonal samples of that pixel in the fp64 arithmetic of skimage's
-                // bilinear_interpolation (operands re-read from the tile), patched into the owner's nibble.
+                // ---- LBP second stage.  Every lane appends its undecided pixels to the wave's queue (positions from
+                // a prefix sum of the counts); then lane l takes queue entry l, l+64, ...: all four diagonal samples
+                // of that pixel in the fp64 arithmetic of skimage's bilinear_interpolation (operands re-read from the
+                // tile), and-ed into the owner's parked word.  And-ing is enough: an undecided sample was parked as 1,
+                // a decided one already has its exact value.
                 const uint32_t cnt = __popc(pend);
                 if (__any(cnt != 0)) {
                     auto lbp_px = [&](int yy, int xx) -> double {
                         if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
                         return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
                     };
-                    // the four diagonal sign bits (samples 1,3,5,7 from bit 3 down; 1 = below the centre) of one pixel
+                    // the four diagonal LBP bits (samples 1,3,5,7 from bit 3 down) of one pixel
                     auto exact_nibble = [&](int y, int xx) -> uint32_t {
                         double n[3][3];
 #pragma unroll
@@ -426,7 +443,12 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
                         const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
                         const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
-                        return ((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu;
+                        return (b1 << 3) | (b3 << 2) | (b5 << 1) | b7;
+                    };
+                    // and-mask that sets the four diagonal bits of pixel e (0 = low half) of a parked word to nib
+                    auto patch_mask = [](uint32_t nib, int e) -> uint32_t {
+                        const int sh = DIAG_SHIFT + 16 * e;
+                        return ~(0xFu << sh) | (nib << sh);
                     };
                     // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
                     // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
@@ -442,21 +464,23 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     // flat regions queue (nearly) every pixel: the lanes are evenly loaded as they are, and each
                     // keeps its own pixels (no queue, no LDS atomics on a shared word)
                     const bool dense = total > QUEUE_ITEMS / 4;
+                    // item: (owner lane << 4) | (row << 1) | pixel, from the position of a flag in pend
+                    auto item_of = [&](uint32_t flags) -> uint32_t {
+                        const uint32_t p = (uint32_t)__ffs(flags) - 1u;
+                        return ((uint32_t)lane << 4) | ((15u - (p & 15u)) << 1) | (p >> 4);
+                    };
                     if (!dense) {
                         uint32_t qpos = inc - cnt;
-                        wsg[2 * lane] = sgd_lo;
-                        wsg[2 * lane + 1] = sgd_hi;
                         while (pend != 0) {
-                            const uint32_t slot = 2 * BLOCK_ROWS - __ffs(pend);  // 0 = row 0 low pixel, 1 = row 0 high pixel, ...
+                            wq[qpos++] = (uint16_t)item_of(pend);
                             pend &= pend - 1;
-                            wq[qpos++] = (uint16_t)(((uint32_t)lane << 4) | slot);
                         }
                         wave_sync();
                     }
                     else if (!BORDER) {
                         // Flat regions first, all rows of the block at once: where the four columns x-1 .. x+2
                         // hold one value over three consecutive rows, both pixels of the middle row have a flat
-                        // neighbourhood and their nibbles come from the table instead of sixteen trips through
+                        // neighbourhood and their bits come from the table instead of sixteen trips through
                         // the fp64 sequence.  Rolled loops: this runs for flat content only and must not cost
                         // the common path registers.
                         const uint8_t* tp = tile + (yb - 1 - y0 + 2) * LPITCH + (x - x0 + GRAY_XOFF) - 1;
@@ -474,7 +498,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         }
                         uint32_t want = 0;
 #pragma unroll
-                        for (int i = 0; i < BLOCK_ROWS; ++i) want |= ((elig >> i) & 1u) * (3u << (2 * (BLOCK_ROWS - 1 - i)));
+                        for (int i = 0; i < BLOCK_ROWS; ++i) want |= ((elig >> i) & 1u) * (HH >> i);
                         want &= pend;
                         if (want != 0) {
                             const uint8_t* tie = a.tie;
@@ -483,21 +507,14 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                             const uint32_t ncc = tie[2 * TIE_COORDS];
                             const uint8_t* tie_lut = tie + TIE_LUT_OFF;
 #pragma unroll 1
-                            for (int i = 0; i < BLOCK_ROWS; i += 2) {
-                                uint32_t l[4];
-#pragma unroll
-                                for (int k = 0; k < 2; ++k) {
-                                    const uint32_t base = ((uint32_t)(crp >> (8 * (i + k))) & 0xFFu) * ncc;
-                                    const uint32_t cv = (((i + k) < 4 ? cv_lo : cv_hi) >> (8 * ((i + k) & 3))) & 0xFFu;
-                                    l[2 * k] = tie_lut[((base + (cc & 0xFFu)) << 8) + cv];
-                                    l[2 * k + 1] = tie_lut[((base + (cc >> 8)) << 8) + cv];
-                                }
-#pragma unroll
-                                for (int k = 0; k < 2; ++k) {
-                                    const int sh = 4 * (BLOCK_ROWS - 1 - (i + k));
-                                    if ((want >> (2 * (BLOCK_ROWS - 1 - (i + k)) + 1)) & 1u) sgd_lo = (sgd_lo & ~(0xFu << sh)) | (l[2 * k] << sh);
-                                    if ((want >> (2 * (BLOCK_ROWS - 1 - (i + k)))) & 1u) sgd_hi = (sgd_hi & ~(0xFu << sh)) | (l[2 * k + 1] << sh);
-                                }
+                            for (int i = 0; i < BLOCK_ROWS; ++i) {
+                                if (((want >> (15 - i)) & 0x00010001u) == 0) continue;
+                                const uint32_t base = ((uint32_t)(crp >> (8 * i)) & 0xFFu) * ncc;
+                                const uint32_t cv = ((i < 4 ? cv_lo : cv_hi) >> (8 * (i & 3))) & 0xFFu;
+                                uint32_t m = 0xFFFFFFFFu;
+                                if ((want >> (15 - i)) & 1u) m &= patch_mask(tie_lut[((base + (cc & 0xFFu)) << 8) + cv], 0);
+                                if ((want >> (31 - i)) & 1u) m &= patch_mask(tie_lut[((base + (cc >> 8)) << 8) + cv], 1);
+                                park[i * 64 + lane] &= m;
                             }
                             pend &= ~want;
                         }
@@ -509,7 +526,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                             active = pend != 0;
                             if (!__any(active)) break;
                             if (active) {
-                                item = ((uint32_t)lane << 4) | (uint32_t)(2 * BLOCK_ROWS - __ffs(pend));
+                                item = item_of(pend);
                                 pend &= pend - 1;
                             }
                         } else {
@@ -519,38 +536,28 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         }
                         if (active) {
                             const int owner = item >> 4, i = (item & 15) >> 1, e = item & 1;
-                            const int sh = 4 * (BLOCK_ROWS - 1 - i);
-                            const uint32_t nib = exact_nibble(yb + i, x0 + 2 * owner + e) << sh;
-                            if (dense) {
-                                if (e) sgd_hi = (sgd_hi & ~(0xFu << sh)) | nib;
-                                else sgd_lo = (sgd_lo & ~(0xFu << sh)) | nib;
-                            } else {
-                                // distinct entries never share a nibble, so the two read-modify-writes need no
-                                // ordering against other lanes; LDS atomics keep each of them whole
-                                atomicAnd(&wsg[2 * owner + e], ~(0xFu << sh));
-                                atomicOr(&wsg[2 * owner + e], nib);
-                            }
+                            const uint32_t m = patch_mask(exact_nibble(yb + i, x0 + 2 * owner + e), e);
+                            // dense: the word is this lane's own; otherwise entries that share a word must not lose
+                            // each other's bits
+                            if (dense) park[i * 64 + owner] &= m;
+                            else atomicAnd(&park[i * 64 + owner], m);
                         }
                     }
-                    if (!dense) {
-                        wave_sync();
-                        sgd_lo = wsg[2 * lane];
-                        sgd_hi = wsg[2 * lane + 1];
-                        wave_sync();  // the next block's queue must not overtake these reads
-                    }
+                    wave_sync();  // patched words are read back below; the next block's queue must not overtake this one's reads
                 }
-                // ---- codes and histogram of this block: the eight sign bits index a table of one-hot 6-bit counters
+                // ---- codes and histogram of this block: a pixel's half of the parked word is the byte offset of its
+                // entry in the table of one-hot 6-bit counters
 #pragma unroll
                 for (int i = 0; i < BLOCK_ROWS; ++i) {
                     const int y = yb + i;
-                    const int sh = 4 * (BLOCK_ROWS - 1 - i);
-                    uint32_t il = ((sgA[i] >> 12) & 0xFu) | (((sgd_lo >> sh) & 0xFu) << 4);
-                    uint32_t ih = ((sgA[i] >> 28) & 0xFu) | (((sgd_hi >> sh) & 0xFu) << 4);
+                    const uint32_t g = park[i * 64 + lane];
+                    uint32_t il = g & 0xFFFFu, ih = g >> 16;
                     if (BORDER) {
-                        il = (y < H && x < W) ? il : (uint32_t)LUT_INVALID;
-                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)LUT_INVALID;
+                        il = (y < H && x < W) ? il : (uint32_t)(LUT_INVALID * sizeof(uint2));
+                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)(LUT_INVALID * sizeof(uint2));
                     }
-                    const uint2 el = lut[il], eh = lut[ih];
+                    const uint2 el = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + il);
+                    const uint2 eh = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + ih);
                     hist_a += el.x + eh.x;
                     hist_b += el.y + eh.y;
                     if (CODES) {
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ uint32_t tile[LROWS * LDW];
     __shared__ uint2 lut[LUT_INVALID + 2];
     __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
-    __shared__ uint32_t wsg[4][128];
+    __shared__ uint32_t park[4][DO_LBP ? BLOCK_ROWS * 64 : 2];
     __shared__ uint32_t red[4][16];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * TILE_W;
@@ -648,14 +655,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         tile[i] = *reinterpret_cast<const uint32_t*>(gp + (int64_t)gy * a.gpitch + x0 + col * 4);
     }
     if (DO_LBP) {
-        // Histogram table.  Index: bits 3..0 = signs of samples 0,2,4,6, bits 7..4 = signs of samples 1,3,5,7
-        // (1 = sample below the centre).  Uniform patterns (at most two 0/1 changes along samples 0..7)
+        // Histogram table.  Index: bits 3..0 = LBP bits of samples 0,2,4,6, bits 7..4 = those of samples 1,3,5,7
+        // (1 = sample >= centre).  Uniform patterns (at most two 0/1 changes along samples 0..7)
         // get their number of ones, everything else P+1 = 9.
         uint32_t pat = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t sa = ((uint32_t)tid >> (3 - k)) & 1u, sd = ((uint32_t)tid >> (7 - k)) & 1u;
-            pat |= ((sa ^ 1u) << (2 * k)) | ((sd ^ 1u) << (2 * k + 1));  // LBP bit of sample s at bit s
+            pat |= (sa << (2 * k)) | (sd << (2 * k + 1));  // LBP bit of sample s at bit s
         }
         const int changes = __popc((pat ^ (pat >> 1)) & 0x7Fu);
         const int code = (changes <= 2) ? __popc(pat) : 9;
@@ -672,9 +679,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wsg[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], park[wv], frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wsg[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], park[wv], frame, x0, y0, lane, wv, red[wv]);
     } else if ((ys >> 6) < a.bm_words) {
         // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
         const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
@@ -696,18 +703,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         a.part[tileid * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
     }
 }
-
-// 16.16 weights (left, right) of one cell row: row weight wr times (1-dc, dc).  The rounding errors
-// are added to epos / eneg (sum of the positive ones, sum of the negative ones' magnitudes).
-static uint32_t weight_pair(double wr, double dc, double* epos, double* eneg) {
-    const double wl = 65536.0 * wr * (1.0 - dc), wh = 65536.0 * wr * dc;
-    const long long l = llround(wl), r = llround(wh);
-    const double el = (double)l - wl, er = (double)r - wh;
-    *epos += (el > 0 ? el : 0) + (er > 0 ? er : 0);
-    *eneg += (el < 0 ? -el : 0) + (er < 0 ? -er : 0);
-    return (uint32_t)l | ((uint32_t)r << 16);
-}
-static double frac(double v) { return v - floor(v); }
 
 // Tables for flat neighbourhoods, in the layout StencilArgs::tie describes.
 void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_cls_c) {
@@ -737,7 +732,7 @@ void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_
                 const double d = (double)v;
                 const uint32_t b1 = lbp_bit(d, d, d, d, drN, dcP, d), b3 = lbp_bit(d, d, d, d, drN, dcN, d);
                 const uint32_t b5 = lbp_bit(d, d, d, d, drP, dcN, d), b7 = lbp_bit(d, d, d, d, drP, dcP, d);
-                lut[(r * ccls.size() + k) * 256 + v] = (uint8_t)((((b1 << 3) | (b3 << 2) | (b5 << 1) | b7) ^ 0xFu));
+                lut[(r * ccls.size() + k) * 256 + v] = (uint8_t)((b1 << 3) | (b3 << 2) | (b5 << 1) | b7);
             }
 }
 
@@ -757,21 +752,10 @@ void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom
     a.high2 = hi | (hi << 16);
     // (P=8,R=1): samples 1,3 sit above the centre (rp<0), 5,7 below; 1,7 right (cp>0), 3,5 left
     a.rp_neg = off.rp[1]; a.rp_pos = off.rp[5]; a.cp_pos = off.cp[1]; a.cp_neg = off.cp[3];
-    const double drN = frac(a.rp_neg), drP = frac(a.rp_pos), dcP = frac(a.cp_pos), dcN = frac(a.cp_neg);
-    // With pixels in [0,255] the fixed-point sample is off by at most 255 * (sum of the one-sided weight
-    // errors); the guard of 2 covers the 1e-12 spread of the per-pixel fp64 weights and fp64 rounding.
-    double worst = 0.0;
-    auto sample_weights = [&](double dr, double dc, uint32_t* top, uint32_t* bottom) {
-        double ep = 0.0, en = 0.0;
-        *top = weight_pair(1.0 - dr, dc, &ep, &en);
-        *bottom = weight_pair(dr, dc, &ep, &en);
-        worst = fmax(worst, 255.0 * fmax(ep, en));
-    };
-    sample_weights(drN, dcP, &a.w1t, &a.w1b);
-    sample_weights(drN, dcN, &a.w3t, &a.w3b);
-    sample_weights(drP, dcN, &a.w5t, &a.w5b);
-    sample_weights(drP, dcP, &a.w7t, &a.w7b);
-    a.margin = (uint32_t)ceil(worst) + 2u;
+    // the integer pre-decision of the diagonal samples is written for the offsets skimage uses at (P=8, R=1)
+    if (do_lbp81 && (llround(a.rp_neg * 1e5) != -70711 || llround(a.rp_pos * 1e5) != 70711 ||
+                     llround(a.cp_pos * 1e5) != 70711 || llround(a.cp_neg * 1e5) != -70711))
+        abort();
     a.part = part;
     a.strong = reinterpret_cast<uint32_t*>(strong);
     a.cand = reinterpret_cast<uint32_t*>(cand);
