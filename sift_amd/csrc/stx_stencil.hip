@@ -43,6 +43,9 @@ namespace stx {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
+#ifndef STX_STENCIL_WAVES
+#define STX_STENCIL_WAVES 4
+#endif
 constexpr int TILE_W = 128;        // 64 lanes x 2 pixels
 constexpr int WAVE_ROWS = 32;      // rows marched by one wave
 constexpr int BLOCK_ROWS = 8;      // rows per unrolled block
@@ -635,8 +638,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 }
 
 template <bool DO_LBP, bool CODES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stencil_kernel(StencilArgs a) {
-    __shared__ uint32_t tile[LROWS * LDW];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL_WAVES, STX_STENCIL_WAVES))) void stencil_kernel(StencilArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[LROWS * LDW];
     __shared__ uint2 lut[LUT_INVALID + 2];
     __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
     __shared__ uint32_t park[4][DO_LBP ? BLOCK_ROWS * 64 : 2];
@@ -646,13 +649,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int y0 = blockIdx.y * TILE_H;
     const int tid = threadIdx.x;
 
-    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
-    for (int i = tid; i < LROWS * LDW; i += 256) {
-        const int row = i / LDW;
-        const int col = i - row * LDW;
-        int gy = y0 + row;  // padded-plane row of global row y0-2+row
-        gy = gy < a.grows ? gy : a.grows - 1;
-        tile[i] = *reinterpret_cast<const uint32_t*>(gp + (int64_t)gy * a.gpitch + x0 + col * 4);
+    // Tile rows start 64-byte aligned in the padded plane (x0 is a multiple of 128, the pitch of 64) and are
+    // LPITCH = 8 * 16 + 8 bytes long: sixteen lanes per row, nine of them busy (eight 16-byte pieces and the tail),
+    // sixteen rows per pass.  The index arithmetic is a shift and a mask; a flat loop over 32-bit words cost a
+    // division per word and a tenth of the kernel's time.
+    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch + x0;
+    {
+        const int lc = tid & 15;
+        if (lc < 9) {
+            constexpr int PASSES = (LROWS + 15) / 16;
+            uint4 v[PASSES];  // every load is issued before the first store: one memory latency per tile, not nine
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                int gy = y0 + (tid >> 4) + 16 * k;  // padded-plane row of global row y0-2+row
+                gy = gy < a.grows ? gy : a.grows - 1;
+                // the tail lane reads 16 bytes too (the plane's pitch has 64 spare bytes) and keeps 8
+                v[k] = *reinterpret_cast<const uint4*>(gp + (int64_t)gy * a.gpitch + lc * 16);
+            }
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tile) + lc * 16;
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int row = (tid >> 4) + 16 * k;
+                if (row < LROWS) {
+                    uint2* dst = reinterpret_cast<uint2*>(tb + row * LPITCH);
+                    dst[0] = make_uint2(v[k].x, v[k].y);
+                    if (lc < 8) dst[1] = make_uint2(v[k].z, v[k].w);
+                }
+            }
+        }
     }
     if (DO_LBP) {
         // Histogram table.  Index: bits 3..0 = LBP bits of samples 0,2,4,6, bits 7..4 = those of samples 1,3,5,7
