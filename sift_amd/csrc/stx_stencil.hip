@@ -43,6 +43,9 @@ namespace stx {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
+#ifndef STX_ABL
+#define STX_ABL 0
+#endif
 #ifndef STX_STENCIL_WAVES
 #define STX_STENCIL_WAVES 4
 #endif
@@ -53,7 +56,8 @@ constexpr int TILE_H = 4 * WAVE_ROWS;
 constexpr int LROWS = TILE_H + 4;  // rows y0-2 .. y0+TILE_H+1
 constexpr int LPITCH = TILE_W + 8; // bytes: columns x0-4 .. x0+131
 constexpr int LDW = LPITCH / 4;
-constexpr int LUT_INVALID = 256;       // histogram table slot that adds nothing
+constexpr int LUT_INVALID = 256;       // histogram table slots 256..511 add nothing
+constexpr int LUT_ENTRIES = 512;
 constexpr int QUEUE_ITEMS = BLOCK_ROWS * TILE_W;  // pixels of one wave's block of rows
 
 // ---- packed 16-bit helpers (operands travel as plain 32-bit words) ----
@@ -141,6 +145,9 @@ __host__ __device__ __forceinline__ uint32_t lbp_bit(double tl, double tr, doubl
     return (t - centre >= 0.0) ? 1u : 0u;
 }
 
+// LBP code of a table entry: the position of its one-hot counter
+__device__ __forceinline__ uint8_t code_of(uint2 e) { return (uint8_t)(e.x ? (__ffs(e.x) - 1) / 6 : 5 + (__ffs(e.y) - 1) / 6); }
+
 struct StencilArgs {
     const uint8_t* gray;
     int H, W, gpitch, grows, bm_words;
@@ -168,8 +175,9 @@ constexpr int TIE_LUT_OFF = 2 * TIE_COORDS + 256;
 constexpr uint32_t HH = 0x80008000u;  // bit 15 of both halves
 // A pixel's eight LBP bits (1 = sample >= centre) sit at bits 10..3 of its half, which makes the half the byte
 // offset of its entry in the histogram table: samples 1,3,5,7 at bits 10..7, samples 0,2,4,6 at bits 6..3.
-constexpr int DIAG_SHIFT = 7;
 constexpr uint32_t TIE_BAND = 0x00050005u;  // N' + 2 in [0, 5) is undecided
+// an undecided pixel gets bit 11 of its half as well: table offset 2048 and up, the entries that add nothing
+constexpr int UNDECIDED_SHIFT = 4;
 
 // byte selectors for v_perm_b32 over {hi source, lo source}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = zero
 constexpr uint32_t SEL_PAIR = 0x0c010c00;   // (b0, b1) of the low source
@@ -192,7 +200,7 @@ struct RowD {
 
 template <bool BORDER, bool DO_LBP, bool CODES>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const uint2* lut,
-                                      uint16_t* wq /*[QUEUE_ITEMS / 4] per wave*/, uint32_t* park /*[BLOCK_ROWS][64] per wave*/,
+                                      uint16_t* wq /*[QUEUE_ITEMS / 4] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
     const int x = x0 + 2 * lane;  // this lane's pixels: x (low half) and x+1 (high half)
@@ -319,9 +327,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         mag_row(ys, rw[1].d, rw[2].d, rw[3].d, rw[1].sm, rw[3].sm, mg[1]);
     }
 
-    // Ten 6-bit counters for both pixel columns together: bins 0..4 in one word, 5..9 in the other, so that a
-    // row's two table entries are added with one three-operand add per word.  A counter holds at most 63 and
-    // 16 rows add at most 32: the first half of the strip is set aside after two blocks.
+    // Ten 6-bit counters for both pixel columns together: bins 0..4 in one word, 5..9 in the other.  A counter holds
+    // at most 63; 16 rows add at most 32 and the second stage at most 8 more (one per round, 64 queue entries per
+    // round, at most a quarter of the pixels queued): the first half of the strip is set aside after its 16 rows.
     uint32_t hist_a = 0, hist_b = 0, hist_a0 = 0, hist_b0 = 0;
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
     uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, newest row lowest, per half
@@ -330,14 +338,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 #pragma unroll 1
     for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
         const int yb = ys + blk * BLOCK_ROWS;
-        if (BORDER && yb >= H) {  // wave-uniform: nothing left in the image, the remaining bits are zero
-            accS = pk_mul<256>(accS);
-            accC = pk_mul<256>(accC);
-        } else {
+        if (!BORDER || yb < H) {  // wave-uniform: below the image nothing is left to do, the remaining bits are zero
             const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
-            // LBP state of this block: the bit words of the rows go to LDS (park[row][lane]) as they are made, where
-            // the second stage can patch them; pend holds the undecided flags, row i at bit 15-i (low pixel) and
-            // 31-i (high pixel).
+            // pend holds the undecided flags of this block, row i at bit 15-i (low pixel) and 31-i (high pixel)
             uint32_t pend = 0;
 #pragma unroll
             for (int i = 0; i < BLOCK_ROWS; ++i) {
@@ -363,7 +366,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     ad_s = sad_u16(c2, blur, ad_s);
                 }
                 // ---- LBP (P=8, R=1), first stage: bit 15 of each half of a difference is "sample >= centre"
-                if (DO_LBP) {
+                if (DO_LBP && STX_ABL != 3) {
                     const uint32_t a0 = rw[2].zhp - c2;  // sample 0 (0,+1)
                     const uint32_t a2 = rw[1].zh0 - c2;  // sample 2 (-1,0)
                     const uint32_t a4 = rw[2].zhm - c2;  // sample 4 (0,-1)
@@ -376,12 +379,27 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                                           ((f5 >> 7) & 0x01000100u) | ((f7 >> 8) & 0x00800080u) |
                                           ((a0 >> 9) & 0x00400040u) | ((a2 >> 10) & 0x00200020u) |
                                           ((a4 >> 11) & 0x00100010u) | ((a6 >> 12) & 0x00080008u);
-                    park[i * 64 + lane] = bits;
                     // undecided: 0x8000 <= f < 0x8005, i.e. subtracting 5 clears bit 15 (f is at least 0x82)
                     uint32_t und = (f1 ^ (f1 - TIE_BAND)) | (f3 ^ (f3 - TIE_BAND)) | (f5 ^ (f5 - TIE_BAND)) |
                                    (f7 ^ (f7 - TIE_BAND));
-                    if (BORDER) und &= vmy;
-                    pend |= (und & HH) >> i;
+                    und &= BORDER ? (vmy & HH) : HH;
+                    pend |= und >> i;
+                    // histogram (and codes): a pixel's half of the bit word is the byte offset of its entry in the
+                    // table of one-hot 6-bit counters; undecided pixels add nothing here, the second stage adds them
+                    const uint32_t g = bits | (und >> UNDECIDED_SHIFT);
+                    uint32_t il = g & 0xFFFFu, ih = g >> 16;
+                    if (BORDER) {
+                        il = (y < H && x < W) ? il : (uint32_t)(LUT_INVALID * sizeof(uint2));
+                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)(LUT_INVALID * sizeof(uint2));
+                    }
+                    const uint2 el = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + il);
+                    const uint2 eh = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + ih);
+                    hist_a += el.x + eh.x;
+                    hist_b += el.y + eh.y;
+                    if (CODES) {
+                        if (el.x | el.y) a.codes[((int64_t)frame * H + y) * W + x] = code_of(el);
+                        if (eh.x | eh.y) a.codes[((int64_t)frame * H + y) * W + x + 1] = code_of(eh);
+                    }
                 }
                 // ---- Canny non-maximum suppression + double threshold on both pixels at once.  The sign
                 // bit of each 16-bit difference is the predicate; masks select the two neighbours along the
@@ -391,7 +409,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     const uint32_t m = mg[1].M;
                     const uint32_t nz = pk_sub(a.low2, m);  // negative where m > low
                     uint32_t ks = 0, kc = 0;
-                    if (__any((nz & 0x80008000u) != 0)) {
+                    if (STX_ABL != 2 && __any((nz & 0x80008000u) != 0)) {
                         const uint32_t ax = mg[1].ax, ay = mg[1].ay;
                         const uint32_t q22 = pk_shr<7>(pk_mad<53>(ax, pk_shr<8>(pk_mul<5>(ax))));
                         const uint32_t nothoriz = pk_sign_mask(pk_sub(q22, ay));              // |gy| > tan22 |gx|
@@ -420,23 +438,30 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             }
             if (DO_LBP) {
                 // ---- LBP second stage.  Every lane appends its undecided pixels to the wave's queue (positions from
-                // a prefix sum of the counts); then lane l takes queue entry l, l+64, ...: all four diagonal samples
-                // of that pixel in the fp64 arithmetic of skimage's bilinear_interpolation (operands re-read from the
-                // tile), and-ed into the owner's parked word.  And-ing is enough: an undecided sample was parked as 1,
-                // a decided one already has its exact value.
+                // a prefix sum of the counts); then lane l takes queue entry l, l+64, ...: the pixel's four axis bits
+                // again and all four diagonal samples in the fp64 arithmetic of skimage's bilinear_interpolation
+                // (operands re-read from the tile), and adds the pixel to its own histogram counters -- which lane
+                // counts a pixel does not matter.
                 const uint32_t cnt = __popc(pend);
-                if (__any(cnt != 0)) {
-                    auto lbp_px = [&](int yy, int xx) -> double {
-                        if (BORDER && (yy < 0 || yy >= H || xx < 0 || xx >= W)) return 0.0;
-                        return (double)tile[(yy - y0 + 2) * LPITCH + (xx - x0 + GRAY_XOFF)];
+                if (STX_ABL != 1 && __any(cnt != 0)) {
+                    auto count_pixel = [&](uint32_t idx, int y, int xx) {
+                        const uint2 e = lut[idx];
+                        hist_a += e.x;
+                        hist_b += e.y;
+                        if (CODES) a.codes[((int64_t)frame * H + y) * W + xx] = code_of(e);
                     };
-                    // the four diagonal LBP bits (samples 1,3,5,7 from bit 3 down) of one pixel
-                    auto exact_nibble = [&](int y, int xx) -> uint32_t {
+                    // table index of one pixel with every sample evaluated exactly
+                    auto exact_index = [&](int y, int xx) -> uint32_t {
                         double n[3][3];
 #pragma unroll
                         for (int r = 0; r < 3; ++r)
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) n[r][q] = lbp_px(y - 1 + r, xx - 1 + q);
+                            for (int q = 0; q < 3; ++q) {
+                                const int yy = y - 1 + r, xq = xx - 1 + q;
+                                n[r][q] = (BORDER && (yy < 0 || yy >= H || xq < 0 || xq >= W))
+                                              ? 0.0
+                                              : (double)tile[(yy - y0 + 2) * LPITCH + (xq - x0 + GRAY_XOFF)];
+                            }
                         const double rfn = (double)y + a.rp_neg, rfp = (double)y + a.rp_pos;
                         const double drN = rfn - floor(rfn), drP = rfp - floor(rfp);
                         const double cfp = (double)xx + a.cp_pos, cfn = (double)xx + a.cp_neg;
@@ -446,12 +471,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
                         const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
                         const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
-                        return (b1 << 3) | (b3 << 2) | (b5 << 1) | b7;
-                    };
-                    // and-mask that sets the four diagonal bits of pixel e (0 = low half) of a parked word to nib
-                    auto patch_mask = [](uint32_t nib, int e) -> uint32_t {
-                        const int sh = DIAG_SHIFT + 16 * e;
-                        return ~(0xFu << sh) | (nib << sh);
+                        const uint32_t b0 = n[1][2] >= ce, b2 = n[0][1] >= ce, b4 = n[1][0] >= ce, b6 = n[2][1] >= ce;
+                        return (b1 << 7) | (b3 << 6) | (b5 << 5) | (b7 << 4) | (b0 << 3) | (b2 << 2) | (b4 << 1) | b6;
                     };
                     // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
                     // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
@@ -465,12 +486,12 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     // flat regions queue (nearly) every pixel: the lanes are evenly loaded as they are, and each
-                    // keeps its own pixels (no queue, no LDS atomics on a shared word)
+                    // keeps its own pixels (no queue)
                     const bool dense = total > QUEUE_ITEMS / 4;
-                    // item: (owner lane << 4) | (row << 1) | pixel, from the position of a flag in pend
+                    // item: (owner lane << 5) | (row << 1) | pixel, from the position of a flag in pend
                     auto item_of = [&](uint32_t flags) -> uint32_t {
                         const uint32_t p = (uint32_t)__ffs(flags) - 1u;
-                        return ((uint32_t)lane << 4) | ((15u - (p & 15u)) << 1) | (p >> 4);
+                        return ((uint32_t)lane << 5) | ((15u - (p & 15u)) << 1) | (p >> 4);
                     };
                     if (!dense) {
                         uint32_t qpos = inc - cnt;
@@ -481,22 +502,21 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         wave_sync();
                     }
                     else if (!BORDER) {
-                        // Flat regions first, all rows of the block at once: where the four columns x-1 .. x+2
-                        // hold one value over three consecutive rows, both pixels of the middle row have a flat
-                        // neighbourhood and their bits come from the table instead of sixteen trips through
-                        // the fp64 sequence.  Rolled loops: this runs for flat content only and must not cost
-                        // the common path registers.
+                        // Flat regions first: where the four columns x-1 .. x+2 hold one value over three consecutive
+                        // rows, both pixels of the middle row have a flat neighbourhood; their axis bits are all set
+                        // and their diagonal bits come from the table instead of trips through the fp64 sequence.
+                        // Rolled loops: this runs for flat content only and must not cost the common path registers.
+                        // The queue is idle in this mode: BLOCK_ROWS of its bytes per lane hold the rows' centre values.
                         const uint8_t* tp = tile + (yb - 1 - y0 + 2) * LPITCH + (x - x0 + GRAY_XOFF) - 1;
+                        uint8_t* cvb = reinterpret_cast<uint8_t*>(wq) + lane * BLOCK_ROWS;
                         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0, elig = 0;
-                        uint32_t cv_lo = 0, cv_hi = 0;  // centre values of rows 0..3 / 4..7, one byte each
 #pragma unroll 1
                         for (int r = 0; r < BLOCK_ROWS + 2; ++r) {
                             const uint32_t b0 = tp[r * LPITCH], b1 = tp[r * LPITCH + 1], b2 = tp[r * LPITCH + 2],
                                            b3 = tp[r * LPITCH + 3];
                             const uint32_t f = (((b0 ^ b1) | (b1 ^ b2) | (b2 ^ b3)) == 0) ? 1u : 0u;
                             if (r >= 2 && (f & f1 & f0) != 0 && b0 == v1 && v1 == v0) elig |= 1u << (r - 2);
-                            if (r >= 1 && r <= 4) cv_lo |= b1 << (8 * (r - 1));
-                            if (r >= 5 && r <= 8) cv_hi |= b1 << (8 * (r - 5));
+                            if (r >= 1 && r <= BLOCK_ROWS) cvb[r - 1] = (uint8_t)b1;
                             f0 = f1; v0 = v1; f1 = f; v1 = b0;
                         }
                         uint32_t want = 0;
@@ -506,18 +526,23 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         if (want != 0) {
                             const uint8_t* tie = a.tie;
                             const uint32_t cc = *reinterpret_cast<const uint16_t*>(tie + TIE_COORDS + x);
-                            const unsigned long long crp = *reinterpret_cast<const unsigned long long*>(tie + yb);
                             const uint32_t ncc = tie[2 * TIE_COORDS];
                             const uint8_t* tie_lut = tie + TIE_LUT_OFF;
 #pragma unroll 1
-                            for (int i = 0; i < BLOCK_ROWS; ++i) {
-                                if (((want >> (15 - i)) & 0x00010001u) == 0) continue;
-                                const uint32_t base = ((uint32_t)(crp >> (8 * i)) & 0xFFu) * ncc;
-                                const uint32_t cv = ((i < 4 ? cv_lo : cv_hi) >> (8 * (i & 3))) & 0xFFu;
-                                uint32_t m = 0xFFFFFFFFu;
-                                if ((want >> (15 - i)) & 1u) m &= patch_mask(tie_lut[((base + (cc & 0xFFu)) << 8) + cv], 0);
-                                if ((want >> (31 - i)) & 1u) m &= patch_mask(tie_lut[((base + (cc >> 8)) << 8) + cv], 1);
-                                park[i * 64 + lane] &= m;
+                            for (int i = 0; i < BLOCK_ROWS; i += 2) {
+                                uint32_t l[4];
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const uint32_t base = (uint32_t)tie[yb + i + k] * ncc;
+                                    const uint32_t cv = cvb[i + k];
+                                    l[2 * k] = tie_lut[((base + (cc & 0xFFu)) << 8) + cv];
+                                    l[2 * k + 1] = tie_lut[((base + (cc >> 8)) << 8) + cv];
+                                }
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    if ((want >> (15 - (i + k))) & 1u) count_pixel((l[2 * k] << 4) | 0xFu, yb + i + k, x);
+                                    if ((want >> (31 - (i + k))) & 1u) count_pixel((l[2 * k + 1] << 4) | 0xFu, yb + i + k, x + 1);
+                                }
                             }
                             pend &= ~want;
                         }
@@ -538,40 +563,19 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                             if (active) item = wq[qb + lane];
                         }
                         if (active) {
-                            const int owner = item >> 4, i = (item & 15) >> 1, e = item & 1;
-                            const uint32_t m = patch_mask(exact_nibble(yb + i, x0 + 2 * owner + e), e);
-                            // dense: the word is this lane's own; otherwise entries that share a word must not lose
-                            // each other's bits
-                            if (dense) park[i * 64 + owner] &= m;
-                            else atomicAnd(&park[i * 64 + owner], m);
+                            const int owner = item >> 5, i = (item & 31) >> 1, e = item & 1;
+                            const int y = yb + i, xx = x0 + 2 * owner + e;
+                            count_pixel(exact_index(y, xx), y, xx);
                         }
                     }
-                    wave_sync();  // patched words are read back below; the next block's queue must not overtake this one's reads
-                }
-                // ---- codes and histogram of this block: a pixel's half of the parked word is the byte offset of its
-                // entry in the table of one-hot 6-bit counters
-#pragma unroll
-                for (int i = 0; i < BLOCK_ROWS; ++i) {
-                    const int y = yb + i;
-                    const uint32_t g = park[i * 64 + lane];
-                    uint32_t il = g & 0xFFFFu, ih = g >> 16;
-                    if (BORDER) {
-                        il = (y < H && x < W) ? il : (uint32_t)(LUT_INVALID * sizeof(uint2));
-                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)(LUT_INVALID * sizeof(uint2));
-                    }
-                    const uint2 el = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + il);
-                    const uint2 eh = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + ih);
-                    hist_a += el.x + eh.x;
-                    hist_b += el.y + eh.y;
-                    if (CODES) {
-                        auto code_of = [](uint2 e) -> uint8_t { return (uint8_t)(e.x ? (__ffs(e.x) - 1) / 6 : 5 + (__ffs(e.y) - 1) / 6); };
-                        if (el.x | el.y) a.codes[((int64_t)frame * H + y) * W + x] = code_of(el);
-                        if (eh.x | eh.y) a.codes[((int64_t)frame * H + y) * W + x + 1] = code_of(eh);
-                    }
+                    if (!dense) wave_sync();  // the next block's queue must not overtake this one's reads
                 }
             }
+        } else if (BLOCK_ROWS < 16) {
+            accS = pk_mul<(1 << (BLOCK_ROWS & 15))>(accS);
+            accC = pk_mul<(1 << (BLOCK_ROWS & 15))>(accC);
         }
-        if (blk == 1) {
+        if (blk == WAVE_ROWS / BLOCK_ROWS / 2 - 1) {
             accS0 = accS; accC0 = accC;
             accS = 0; accC = 0;
             hist_a0 = hist_a; hist_b0 = hist_b;
@@ -640,9 +644,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
 template <bool DO_LBP, bool CODES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL_WAVES, STX_STENCIL_WAVES))) void stencil_kernel(StencilArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LROWS * LDW];
-    __shared__ uint2 lut[LUT_INVALID + 2];
+    __shared__ uint2 lut[LUT_ENTRIES];
     __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
-    __shared__ uint32_t park[4][DO_LBP ? BLOCK_ROWS * 64 : 2];
     __shared__ uint32_t red[4][16];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * TILE_W;
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
         const int changes = __popc((pat ^ (pat >> 1)) & 0x7Fu);
         const int code = (changes <= 2) ? __popc(pat) : 9;
         lut[tid] = code < 5 ? make_uint2(1u << (6 * code), 0u) : make_uint2(0u, 1u << (6 * (code - 5)));
-        if (tid < 2) lut[LUT_INVALID + tid] = make_uint2(0u, 0u);
+        lut[LUT_INVALID + tid] = make_uint2(0u, 0u);
     }
     if (tid < 64) red[tid >> 4][tid & 15] = 0;
     __syncthreads();
@@ -703,9 +706,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], park[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], park[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], frame, x0, y0, lane, wv, red[wv]);
     } else if ((ys >> 6) < a.bm_words) {
         // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
         const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
