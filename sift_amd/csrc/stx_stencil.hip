@@ -58,7 +58,8 @@ constexpr int LPITCH = TILE_W + 8; // bytes: columns x0-4 .. x0+131
 constexpr int LDW = LPITCH / 4;
 constexpr int LUT_INVALID = 256;       // histogram table slots 256..511 add nothing
 constexpr int LUT_ENTRIES = 512;
-constexpr int QUEUE_ITEMS = BLOCK_ROWS * TILE_W;  // pixels of one wave's block of rows
+constexpr int DENSE_MIN = BLOCK_ROWS * TILE_W / 8;  // a block with more undecided pixels is re-evaluated lane by lane
+constexpr int QUEUE_ITEMS = (WAVE_ROWS / BLOCK_ROWS) * DENSE_MIN;  // what the sparse blocks of a strip can queue
 
 // ---- packed 16-bit helpers (operands travel as plain 32-bit words) ----
 __device__ __forceinline__ us2 asU(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -200,7 +201,7 @@ struct RowD {
 
 template <bool BORDER, bool DO_LBP, bool CODES>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const uint2* lut,
-                                      uint16_t* wq /*[QUEUE_ITEMS / 4] per wave*/,
+                                      uint16_t* wq /*[QUEUE_ITEMS] per wave*/, uint32_t* wpend /*[blocks][64] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
     const int H = a.H, W = a.W;
     const int x = x0 + 2 * lane;  // this lane's pixels: x (low half) and x+1 (high half)
@@ -328,12 +329,43 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     }
 
     // Ten 6-bit counters for both pixel columns together: bins 0..4 in one word, 5..9 in the other.  A counter holds
-    // at most 63; 16 rows add at most 32 and the second stage at most 8 more (one per round, 64 queue entries per
-    // round, at most a quarter of the pixels queued): the first half of the strip is set aside after its 16 rows.
+    // at most 63; 16 rows add at most 32 (whichever lane counts a pixel in a dense block, it is one of its own) and
+    // the second stage at most QUEUE_ITEMS / 64 = 8 more: the first half of the strip is set aside after its 16 rows.
     uint32_t hist_a = 0, hist_b = 0, hist_a0 = 0, hist_b0 = 0;
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
     uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, newest row lowest, per half
     uint32_t accS0 = 0, accC0 = 0;    // rows 0..15 of the strip
+
+    auto count_pixel = [&](uint32_t idx, int y, int xx) {
+        const uint2 e = lut[idx];
+        hist_a += e.x;
+        hist_b += e.y;
+        if (CODES) a.codes[((int64_t)frame * H + y) * W + xx] = code_of(e);
+    };
+    // table index of one pixel with every sample evaluated exactly
+    auto exact_index = [&](int y, int xx) -> uint32_t {
+        double n[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int yy = y - 1 + r, xq = xx - 1 + q;
+                n[r][q] = (BORDER && (yy < 0 || yy >= H || xq < 0 || xq >= W))
+                              ? 0.0
+                              : (double)tile[(yy - y0 + 2) * LPITCH + (xq - x0 + GRAY_XOFF)];
+            }
+        const double rfn = (double)y + a.rp_neg, rfp = (double)y + a.rp_pos;
+        const double drN = rfn - floor(rfn), drP = rfp - floor(rfp);
+        const double cfp = (double)xx + a.cp_pos, cfn = (double)xx + a.cp_neg;
+        const double dcP = cfp - floor(cfp), dcN = cfn - floor(cfn);
+        const double ce = n[1][1];
+        const uint32_t b1 = lbp_bit(n[0][1], n[0][2], n[1][1], n[1][2], drN, dcP, ce);
+        const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
+        const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
+        const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
+        const uint32_t b0 = n[1][2] >= ce, b2 = n[0][1] >= ce, b4 = n[1][0] >= ce, b6 = n[2][1] >= ce;
+        return (b1 << 7) | (b3 << 6) | (b5 << 5) | (b7 << 4) | (b0 << 3) | (b2 << 2) | (b4 << 1) | b6;
+    };
 
 #pragma unroll 1
     for (int blk = 0; blk < WAVE_ROWS / BLOCK_ROWS; ++blk) {
@@ -436,77 +468,20 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 mg[0] = mg[1];
                 mg[1] = mg[2];
             }
-            if (DO_LBP) {
-                // ---- LBP second stage.  Every lane appends its undecided pixels to the wave's queue (positions from
-                // a prefix sum of the counts); then lane l takes queue entry l, l+64, ...: the pixel's four axis bits
-                // again and all four diagonal samples in the fp64 arithmetic of skimage's bilinear_interpolation
-                // (operands re-read from the tile), and adds the pixel to its own histogram counters -- which lane
-                // counts a pixel does not matter.
-                const uint32_t cnt = __popc(pend);
-                if (STX_ABL != 1 && __any(cnt != 0)) {
-                    auto count_pixel = [&](uint32_t idx, int y, int xx) {
-                        const uint2 e = lut[idx];
-                        hist_a += e.x;
-                        hist_b += e.y;
-                        if (CODES) a.codes[((int64_t)frame * H + y) * W + xx] = code_of(e);
-                    };
-                    // table index of one pixel with every sample evaluated exactly
-                    auto exact_index = [&](int y, int xx) -> uint32_t {
-                        double n[3][3];
+            if (DO_LBP && STX_ABL != 1) {
+                // ---- undecided pixels of this block.  Normally few: their flags wait in LDS for the end of the strip.
+                // Flat regions flag (nearly) every pixel: then the lanes are evenly loaded as they are and each
+                // re-evaluates its own pixels here.
+                uint32_t tot = __popc(pend);
 #pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) {
-                                const int yy = y - 1 + r, xq = xx - 1 + q;
-                                n[r][q] = (BORDER && (yy < 0 || yy >= H || xq < 0 || xq >= W))
-                                              ? 0.0
-                                              : (double)tile[(yy - y0 + 2) * LPITCH + (xq - x0 + GRAY_XOFF)];
-                            }
-                        const double rfn = (double)y + a.rp_neg, rfp = (double)y + a.rp_pos;
-                        const double drN = rfn - floor(rfn), drP = rfp - floor(rfp);
-                        const double cfp = (double)xx + a.cp_pos, cfn = (double)xx + a.cp_neg;
-                        const double dcP = cfp - floor(cfp), dcN = cfn - floor(cfn);
-                        const double ce = n[1][1];
-                        const uint32_t b1 = lbp_bit(n[0][1], n[0][2], n[1][1], n[1][2], drN, dcP, ce);
-                        const uint32_t b3 = lbp_bit(n[0][0], n[0][1], n[1][0], n[1][1], drN, dcN, ce);
-                        const uint32_t b5 = lbp_bit(n[1][0], n[1][1], n[2][0], n[2][1], drP, dcN, ce);
-                        const uint32_t b7 = lbp_bit(n[1][1], n[1][2], n[2][1], n[2][2], drP, dcP, ce);
-                        const uint32_t b0 = n[1][2] >= ce, b2 = n[0][1] >= ce, b4 = n[1][0] >= ce, b6 = n[2][1] >= ce;
-                        return (b1 << 7) | (b3 << 6) | (b5 << 5) | (b7 << 4) | (b0 << 3) | (b2 << 2) | (b4 << 1) | b6;
-                    };
-                    // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
-                    // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
-                    // next row, then lane 31 into the upper half
-                    uint32_t inc = cnt;
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);  // row_bcast:15
-                    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                    // flat regions queue (nearly) every pixel: the lanes are evenly loaded as they are, and each
-                    // keeps its own pixels (no queue)
-                    const bool dense = total > QUEUE_ITEMS / 4;
-                    // item: (owner lane << 5) | (row << 1) | pixel, from the position of a flag in pend
-                    auto item_of = [&](uint32_t flags) -> uint32_t {
-                        const uint32_t p = (uint32_t)__ffs(flags) - 1u;
-                        return ((uint32_t)lane << 5) | ((15u - (p & 15u)) << 1) | (p >> 4);
-                    };
-                    if (!dense) {
-                        uint32_t qpos = inc - cnt;
-                        while (pend != 0) {
-                            wq[qpos++] = (uint16_t)item_of(pend);
-                            pend &= pend - 1;
-                        }
-                        wave_sync();
-                    }
-                    else if (!BORDER) {
-                        // Flat regions first: where the four columns x-1 .. x+2 hold one value over three consecutive
-                        // rows, both pixels of the middle row have a flat neighbourhood; their axis bits are all set
-                        // and their diagonal bits come from the table instead of trips through the fp64 sequence.
-                        // Rolled loops: this runs for flat content only and must not cost the common path registers.
-                        // The queue is idle in this mode: BLOCK_ROWS of its bytes per lane hold the rows' centre values.
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                if (tot > DENSE_MIN) {
+                    if (!BORDER) {
+                        // Flat neighbourhoods first: where the four columns x-1 .. x+2 hold one value over three
+                        // consecutive rows, both pixels of the middle row have all axis bits set and their diagonal
+                        // bits come from the table instead of trips through the fp64 sequence.  Rolled loops: this
+                        // runs for flat content only and must not cost the common path registers.  The queue is idle
+                        // here: BLOCK_ROWS of its bytes per lane hold the rows' centre values.
                         const uint8_t* tp = tile + (yb - 1 - y0 + 2) * LPITCH + (x - x0 + GRAY_XOFF) - 1;
                         uint8_t* cvb = reinterpret_cast<uint8_t*>(wq) + lane * BLOCK_ROWS;
                         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0, elig = 0;
@@ -547,39 +522,78 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                             pend &= ~want;
                         }
                     }
-                    for (uint32_t qb = 0;; qb += 64) {
-                        bool active;
-                        uint32_t item = 0;
-                        if (dense) {
-                            active = pend != 0;
-                            if (!__any(active)) break;
-                            if (active) {
-                                item = item_of(pend);
-                                pend &= pend - 1;
-                            }
-                        } else {
-                            if (qb >= total) break;
-                            active = qb + lane < total;
-                            if (active) item = wq[qb + lane];
-                        }
-                        if (active) {
-                            const int owner = item >> 5, i = (item & 31) >> 1, e = item & 1;
-                            const int y = yb + i, xx = x0 + 2 * owner + e;
+                    while (__any(pend != 0)) {
+                        if (pend != 0) {
+                            const uint32_t p = (uint32_t)__ffs(pend) - 1u;
+                            pend &= pend - 1;
+                            const int y = yb + 15 - (int)(p & 15u), xx = x + (int)(p >> 4);
                             count_pixel(exact_index(y, xx), y, xx);
                         }
                     }
-                    if (!dense) wave_sync();  // the next block's queue must not overtake this one's reads
                 }
+                wpend[blk * 64 + lane] = pend;
             }
-        } else if (BLOCK_ROWS < 16) {
-            accS = pk_mul<(1 << (BLOCK_ROWS & 15))>(accS);
-            accC = pk_mul<(1 << (BLOCK_ROWS & 15))>(accC);
+        } else {
+            if (DO_LBP) wpend[blk * 64 + lane] = 0;
+            if (BLOCK_ROWS < 16) {
+                accS = pk_mul<(1 << (BLOCK_ROWS & 15))>(accS);
+                accC = pk_mul<(1 << (BLOCK_ROWS & 15))>(accC);
+            }
         }
         if (blk == WAVE_ROWS / BLOCK_ROWS / 2 - 1) {
             accS0 = accS; accC0 = accC;
             accS = 0; accC = 0;
             hist_a0 = hist_a; hist_b0 = hist_b;
             hist_a = 0; hist_b = 0;
+        }
+    }
+
+    // ---- LBP second stage.  Every lane appends its undecided pixels to the wave's queue (positions from a prefix sum
+    // of the counts); then lane l takes queue entry l, l+64, ...: the pixel's four axis bits again and all four
+    // diagonal samples in the fp64 arithmetic of skimage's bilinear_interpolation (operands re-read from the tile),
+    // and counts the pixel in its own histogram counters -- which lane counts a pixel does not matter.  One queue
+    // per strip: about 2 % of the pixels of camera-like content are undecided, eighty-odd per strip, two rounds
+    // with most lanes busy (per block of eight rows it was a round with a third of them busy, four times).
+    if (DO_LBP && STX_ABL != 1) {
+        wave_sync();
+        uint32_t pq[WAVE_ROWS / BLOCK_ROWS];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int b = 0; b < WAVE_ROWS / BLOCK_ROWS; ++b) {
+            pq[b] = wpend[b * 64 + lane];
+            cnt += __popc(pq[b]);
+        }
+        if (__any(cnt != 0)) {
+            // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
+            // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
+            // next row, then lane 31 into the upper half
+            uint32_t inc = cnt;
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);  // row_bcast:15
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            uint32_t qpos = inc - cnt;
+            // item: (owner lane << 6) | (row of the strip << 1) | pixel, from the position of a flag
+#pragma unroll
+            for (int b = 0; b < WAVE_ROWS / BLOCK_ROWS; ++b) {
+                uint32_t flags = pq[b];
+                while (flags != 0) {
+                    const uint32_t p = (uint32_t)__ffs(flags) - 1u;
+                    flags &= flags - 1;
+                    wq[qpos++] = (uint16_t)(((uint32_t)lane << 6) | ((uint32_t)(b * BLOCK_ROWS + 15 - (int)(p & 15u)) << 1) | (p >> 4));
+                }
+            }
+            wave_sync();
+            for (uint32_t qb = 0; qb < total; qb += 64) {
+                if (qb + lane < total) {
+                    const uint32_t item = wq[qb + lane];
+                    const int y = ys + (int)((item & 63u) >> 1), xx = x0 + 2 * (int)(item >> 6) + (int)(item & 1u);
+                    count_pixel(exact_index(y, xx), y, xx);
+                }
+            }
         }
     }
 
@@ -645,7 +659,8 @@ template <bool DO_LBP, bool CODES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL_WAVES, STX_STENCIL_WAVES))) void stencil_kernel(StencilArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LROWS * LDW];
     __shared__ uint2 lut[LUT_ENTRIES];
-    __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS / 4 : 2];  // longer queues take the per-lane path
+    __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS : 2];
+    __shared__ uint32_t wpend[4][DO_LBP ? (WAVE_ROWS / BLOCK_ROWS) * 64 : 2];
     __shared__ uint32_t red[4][16];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * TILE_W;
@@ -706,9 +721,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
     } else if ((ys >> 6) < a.bm_words) {
         // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
         const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
