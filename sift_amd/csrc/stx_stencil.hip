@@ -241,13 +241,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         const int gy = (v[2][0] - v[0][0]) + 2 * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2]);
         return abs(gx) + abs(gy);
     };
-    // The magnitudes left of lane 0 and right of lane 63 belong to the neighbouring tiles: lane l
-    // computes them once for row ys-1+l, the marching loop fetches them with a lane read.
+    // The magnitudes left of lane 0 and right of lane 63 belong to the neighbouring tiles: lanes compute them once,
+    // the left ones in lane l for row ys-1+l, the right ones in lane 63-l.  Rows are visited in order, and each
+    // visit rotates the two registers by one lane, so that lane 0 / lane 63 hold the current row's value where the
+    // lane shift of the magnitudes leaves its gap.
     int haloL16 = 0, haloR = 0;
-    if (lane < WAVE_ROWS + 2) {
-        haloL16 = mag_at(ys - 1 + lane, x0 - 1) << 16;  // lands in the high half: the pair (x0-2, x0-1)
-        haloR = mag_at(ys - 1 + lane, x0 + TILE_W);     // low half of the pair (x0+128, x0+129)
-    }
+    if (lane < WAVE_ROWS + 2) haloL16 = mag_at(ys - 1 + lane, x0 - 1) << 16;  // high half: the pair (x0-2, x0-1)
+    if (lane > 63 - (WAVE_ROWS + 2)) haloR = mag_at(ys - 1 + 63 - lane, x0 + TILE_W);  // low half of (x0+128, x0+129)
 
     // rel: row index relative to ys-2 (0 .. WAVE_ROWS+3); off: LDS byte offset of (that row, column x-2)
     const uint32_t wave_off = (uint32_t)((wv * WAVE_ROWS) * LPITCH + 2 * lane + 2);
@@ -306,11 +306,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         o.sxy = gx ^ gy;
         uint32_t m = o.ax + o.ay;  // at most 2040 per half
         if (BORDER) m &= (r >= 0 && r < H) ? vm : 0u;
-        const int rel = r - (ys - 1);
-        const int hl = __builtin_amdgcn_readlane(haloL16, rel);
-        const int hr = __builtin_amdgcn_readlane(haloR, rel);
-        const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(hl, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(hr, (int)m, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(haloL16, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(haloR, (int)m, 0x130, 0xf, 0xf, false);    // wave_shl:1
+        haloL16 = __builtin_amdgcn_update_dpp(0, haloL16, 0x134, 0xf, 0xf, false);  // wave_rol:1, lane i takes lane i+1
+        haloR = __builtin_amdgcn_update_dpp(0, haloR, 0x13C, 0xf, 0xf, false);      // wave_ror:1, lane i takes lane i-1
         o.M = m;
         o.ML = __builtin_amdgcn_alignbit(m, mp, 16);
         o.MR = __builtin_amdgcn_alignbit(mn, m, 16);
@@ -407,10 +406,14 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     const uint32_t f3 = rw[1].rm + rw[2].gm;  // (-.7,-.7)
                     const uint32_t f5 = rw[3].rm + rw[2].gm;  // (+.7,-.7)
                     const uint32_t f7 = rw[3].rp + rw[2].gp;  // (+.7,+.7)
-                    const uint32_t bits = ((f1 >> 5) & 0x04000400u) | ((f3 >> 6) & 0x02000200u) |
-                                          ((f5 >> 7) & 0x01000100u) | ((f7 >> 8) & 0x00800080u) |
-                                          ((a0 >> 9) & 0x00400040u) | ((a2 >> 10) & 0x00200020u) |
-                                          ((a4 >> 11) & 0x00100010u) | ((a6 >> 12) & 0x00080008u);
+                    uint32_t bits = (f1 >> 5) & 0x04000400u;
+                    bits = bfi(0x02000200u, f3 >> 6, bits);
+                    bits = bfi(0x01000100u, f5 >> 7, bits);
+                    bits = bfi(0x00800080u, f7 >> 8, bits);
+                    bits = bfi(0x00400040u, a0 >> 9, bits);
+                    bits = bfi(0x00200020u, a2 >> 10, bits);
+                    bits = bfi(0x00100010u, a4 >> 11, bits);
+                    bits = bfi(0x00080008u, a6 >> 12, bits);
                     // undecided: 0x8000 <= f < 0x8005, i.e. subtracting 5 clears bit 15 (f is at least 0x82)
                     uint32_t und = (f1 ^ (f1 - TIE_BAND)) | (f3 ^ (f3 - TIE_BAND)) | (f5 ^ (f5 - TIE_BAND)) |
                                    (f7 ^ (f7 - TIE_BAND));
