@@ -43,12 +43,8 @@ namespace stx {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
-#ifndef STX_ABL
-#define STX_ABL 0
-#endif
-#ifndef STX_STENCIL_WAVES
+// waves per SIMD the stencil kernel is compiled for: 128 registers each (3 waves measured 10 % slower, 5 spill)
 #define STX_STENCIL_WAVES 4
-#endif
 constexpr int TILE_W = 128;        // 64 lanes x 2 pixels
 constexpr int WAVE_ROWS = 32;      // rows marched by one wave
 constexpr int BLOCK_ROWS = 8;      // rows per unrolled block
@@ -397,7 +393,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     ad_s = sad_u16(c2, blur, ad_s);
                 }
                 // ---- LBP (P=8, R=1), first stage: bit 15 of each half of a difference is "sample >= centre"
-                if (DO_LBP && STX_ABL != 3) {
+                if (DO_LBP) {
                     const uint32_t a0 = rw[2].zhp - c2;  // sample 0 (0,+1)
                     const uint32_t a2 = rw[1].zh0 - c2;  // sample 2 (-1,0)
                     const uint32_t a4 = rw[2].zhm - c2;  // sample 4 (0,-1)
@@ -444,7 +440,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     const uint32_t m = mg[1].M;
                     const uint32_t nz = pk_sub(a.low2, m);  // negative where m > low
                     uint32_t ks = 0, kc = 0;
-                    if (STX_ABL != 2 && __any((nz & 0x80008000u) != 0)) {
+                    if (__any((nz & 0x80008000u) != 0)) {
                         const uint32_t ax = mg[1].ax, ay = mg[1].ay;
                         const uint32_t q22 = pk_shr<7>(pk_mad<53>(ax, pk_shr<8>(pk_mul<5>(ax))));
                         const uint32_t nothoriz = pk_sign_mask(pk_sub(q22, ay));              // |gy| > tan22 |gx|
@@ -471,7 +467,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 mg[0] = mg[1];
                 mg[1] = mg[2];
             }
-            if (DO_LBP && STX_ABL != 1) {
+            if (DO_LBP) {
                 // ---- undecided pixels of this block.  Normally few: their flags wait in LDS for the end of the strip.
                 // Flat regions flag (nearly) every pixel: then the lanes are evenly loaded as they are and each
                 // re-evaluates its own pixels here.
@@ -557,7 +553,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // and counts the pixel in its own histogram counters -- which lane counts a pixel does not matter.  One queue
     // per strip: about 2 % of the pixels of camera-like content are undecided, eighty-odd per strip, two rounds
     // with most lanes busy (per block of eight rows it was a round with a third of them busy, four times).
-    if (DO_LBP && STX_ABL != 1) {
+    if (DO_LBP) {
         wave_sync();
         uint32_t pq[WAVE_ROWS / BLOCK_ROWS];
         uint32_t cnt = 0;
