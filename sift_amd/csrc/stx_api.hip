@@ -46,10 +46,10 @@ static __device__ __align__(256) unsigned char scratch[STX_NOALLOC_SCRATCH_BYTES
 
 // Layout of the scratch array: four twiddle tables of STX_MAX_DIM entries, then the buffers of one chunk of frames.
 constexpr size_t NA_TW_W = 0;
-constexpr size_t NA_TW_H = NA_TW_W + (size_t)STX_MAX_DIM * sizeof(float2);
-constexpr size_t NA_TW64_W = NA_TW_H + (size_t)STX_MAX_DIM * sizeof(float2);
-constexpr size_t NA_TW64_H = NA_TW64_W + (size_t)STX_MAX_DIM * sizeof(double2);
-constexpr size_t NA_BUFFERS = NA_TW64_H + (size_t)STX_MAX_DIM * sizeof(double2);
+constexpr size_t NA_TW_H = NA_TW_W + FFT_TABLE_MAX * sizeof(float2);
+constexpr size_t NA_TW64_W = NA_TW_H + FFT_TABLE_MAX * sizeof(float2);
+constexpr size_t NA_TW64_H = NA_TW64_W + FFT_TABLE_MAX * sizeof(double2);
+constexpr size_t NA_BUFFERS = NA_TW64_H + FFT_TABLE_MAX * sizeof(double2);
 constexpr int NA_MAX_CHUNK = 64;  // frames per pass over the scratch array (the pinned result staging holds this many)
 
 // Everything derived from (frame size, parameters) that the kernels of one call need.
@@ -102,7 +102,7 @@ struct stx_ctx {
     // stx_analyze_batch_device_noalloc
     uint8_t* na_base = nullptr;        // device address of this GPU's copy of the scratch array
     Slot na;                           // its buffers point into the scratch array
-    void* na_stage = nullptr;          // pinned host staging for twiddle uploads (STX_MAX_DIM double2)
+    void* na_stage = nullptr;          // pinned host staging for table uploads (FFT_TABLE_MAX double2, then as many float2)
     int na_tw_n[4] = {0, 0, 0, 0};     // lengths of the tables currently in the scratch array
     int tie_ncls = 0;
     double tie_key[4] = {0, 0, 0, 0};  // the offsets the tie tables were built for
@@ -195,34 +195,45 @@ void collect_spans(stx_ctx* c, std::vector<TimedSpan>& spans) {
     spans.clear();
 }
 
-int get_twiddles(stx_ctx* c, int n, float2** out) {
-    auto it = c->twiddles.find(n);
+// The table a plan's kernels read (twiddles, or the chirp-z tables of a length with a large prime factor), one per
+// length and precision, kept for the life of the context.
+int get_twiddles(stx_ctx* c, const FftPlan& plan, float2** out) {
+    auto it = c->twiddles.find(plan.n);
     if (it != c->twiddles.end()) { *out = it->second; return STX_OK; }
-    std::vector<float2> h((size_t)n);
-    for (int k = 0; k < n; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)n;
-        h[k] = make_float2((float)cos(a), (float)sin(a));
+    const size_t entries = fft_table_entries(plan);
+    std::vector<double> t;
+    std::vector<float2> h;
+    try {
+        t.resize(2 * entries);
+        h.resize(entries);
+    } catch (const std::bad_alloc&) {
+        return fail(c, STX_ERR_NOMEM, "out of host memory");
     }
+    fft_fill_table(plan, t.data());
+    for (size_t k = 0; k < entries; ++k) h[k] = make_float2((float)t[2 * k], (float)t[2 * k + 1]);
     float2* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, sizeof(float2) * (size_t)n));
-    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-    c->twiddles[n] = d;
+    HIPCHK(c, hipMalloc(&d, sizeof(float2) * entries));
+    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(float2) * entries, hipMemcpyHostToDevice));
+    c->twiddles[plan.n] = d;
     *out = d;
     return STX_OK;
 }
 
-int get_twiddles64(stx_ctx* c, int n, void** out) {
-    auto it = c->twiddles64.find(n);
+int get_twiddles64(stx_ctx* c, const FftPlan& plan, void** out) {
+    auto it = c->twiddles64.find(plan.n);
     if (it != c->twiddles64.end()) { *out = it->second; return STX_OK; }
-    std::vector<double2> h((size_t)n);
-    for (int k = 0; k < n; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)n;
-        h[k] = make_double2(cos(a), sin(a));
+    const size_t entries = fft_table_entries(plan);
+    std::vector<double> t;
+    try {
+        t.resize(2 * entries);
+    } catch (const std::bad_alloc&) {
+        return fail(c, STX_ERR_NOMEM, "out of host memory");
     }
+    fft_fill_table(plan, t.data());
     void* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, sizeof(double2) * (size_t)n));
-    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
-    c->twiddles64[n] = d;
+    HIPCHK(c, hipMalloc(&d, sizeof(double2) * entries));
+    HIPCHK(c, hipMemcpy(d, t.data(), sizeof(double2) * entries, hipMemcpyHostToDevice));
+    c->twiddles64[plan.n] = d;
     *out = d;
     return STX_OK;
 }
@@ -398,11 +409,11 @@ int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr, bo
     HIPCHK(c, hipSetDevice(c->device));
     if (!make_fft_plan(pr->g.fw, &pr->plan_w) || !make_fft_plan(pr->g.fh, &pr->plan_h))
         return fail(c, STX_ERR_UNSUPPORTED, "FFT size has too many prime factors");
-    pr->lay = fft_choose_layout(pr->g);
+    pr->lay = fft_choose_layout(pr->g, pr->plan_h);
     pr->tw_w = pr->tw_h = nullptr;
     if (own_twiddles) {
-        if ((rc = get_twiddles(c, pr->g.fw, &pr->tw_w)) != STX_OK) return rc;
-        if ((rc = get_twiddles(c, pr->g.fh, &pr->tw_h)) != STX_OK) return rc;
+        if ((rc = get_twiddles(c, pr->plan_w, &pr->tw_w)) != STX_OK) return rc;
+        if ((rc = get_twiddles(c, pr->plan_h, &pr->tw_h)) != STX_OK) return rc;
     }
     if (lbp_offsets(pr->p.lbp_points, pr->p.lbp_radius, &pr->off) != 0) return fail(c, STX_ERR_INVALID, "bad lbp_points");
     return STX_OK;
@@ -610,12 +621,12 @@ void finalize_extended(const FrameAcc& a, const Geom& g, stx_extended* x) {
 
 // Recomputes fft_sum / fft_sumsq of the listed frames of a finished chunk in double precision (the chunk's gray
 // planes are still in the slot).  One frame at a time: this is the path of rare, synthetic-looking frames.
-int na_twiddles(stx_ctx* c, int which, int n);
+int na_twiddles(stx_ctx* c, int which, const FftPlan& plan);
 
 int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, int n_redo) {
     const Geom& g = pr.g;
     Fft64Work w;
-    fft64_sizes(g, &w.spec_bytes, &w.scratch_bytes, &w.part_bytes);
+    fft64_sizes(g, pr.plan_w, pr.plan_h, &w.spec_bytes, &w.scratch_bytes, &w.part_bytes);
     int rc;
     void *tw_w = nullptr, *tw_h = nullptr;
     double2* part_host;
@@ -625,7 +636,7 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
         w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
         if (c->spec64.cap < w.spec_bytes || c->scratch64.cap < w.scratch_bytes || c->part64.cap < w.part_bytes)
             return fail(c, STX_ERR_NOMEM, "internal: fp64 workspace of the allocation-free path is too small");
-        if ((rc = na_twiddles(c, 2, g.fw)) != STX_OK || (rc = na_twiddles(c, 3, g.fh)) != STX_OK) return rc;
+        if ((rc = na_twiddles(c, 2, pr.plan_w)) != STX_OK || (rc = na_twiddles(c, 3, pr.plan_h)) != STX_OK) return rc;
         tw_w = c->na_base + NA_TW64_W;
         tw_h = c->na_base + NA_TW64_H;
         part_host = (double2*)c->na_stage;
@@ -634,8 +645,8 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
         if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes)) != STX_OK) return rc;
         if ((rc = ensure(c, c->part64, w.part_bytes)) != STX_OK) return rc;
         w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
-        if ((rc = get_twiddles64(c, g.fw, &tw_w)) != STX_OK) return rc;
-        if ((rc = get_twiddles64(c, g.fh, &tw_h)) != STX_OK) return rc;
+        if ((rc = get_twiddles64(c, pr.plan_w, &tw_w)) != STX_OK) return rc;
+        if ((rc = get_twiddles64(c, pr.plan_h, &tw_h)) != STX_OK) return rc;
         try {
             c->part64_host.resize((size_t)g.fwh);
         } catch (const std::bad_alloc&) {
@@ -804,7 +815,7 @@ int stx_create(int device_id, stx_ctx** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->na.changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
     if (e == hipSuccess) {
         *c->na.changed_host = 0;
-        e = hipHostMalloc(&c->na_stage, sizeof(double2) * (size_t)STX_MAX_DIM, hipHostMallocDefault);
+        e = hipHostMalloc(&c->na_stage, (sizeof(double2) + sizeof(float2)) * FFT_TABLE_MAX, hipHostMallocDefault);
     }
     if (e == hipSuccess) { step = "hipEventCreate"; e = hipEventCreateWithFlags(&c->na.done, hipEventDisableTiming); }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.gray_ready, hipEventDisableTiming);
@@ -902,27 +913,26 @@ namespace {
 
 // Twiddle table `which` (0: fp32 rows, 1: fp32 columns, 2: fp64 rows, 3: fp64 columns) of length n in its place in
 // the scratch array; uploaded through the pinned staging only when the length changes.
-int na_twiddles(stx_ctx* c, int which, int n) {
+int na_twiddles(stx_ctx* c, int which, const FftPlan& plan) {
+    const int n = plan.n;
     if (c->na_tw_n[which] == n) return STX_OK;
     static const size_t off[4] = {NA_TW_W, NA_TW_H, NA_TW64_W, NA_TW64_H};
+    const size_t entries = fft_table_entries(plan);
     size_t bytes;
+    const void* src = c->na_stage;
+    // filled in double precision in the first part of the staging; the fp32 tables are narrowed into the second
+    fft_fill_table(plan, (double*)c->na_stage);
     if (which < 2) {
-        float2* h = (float2*)c->na_stage;
-        for (int k = 0; k < n; ++k) {
-            const double a = -2.0 * M_PI * (double)k / (double)n;
-            h[k] = make_float2((float)cos(a), (float)sin(a));
-        }
-        bytes = sizeof(float2) * (size_t)n;
+        const double* t = (const double*)c->na_stage;
+        float2* h = (float2*)((char*)c->na_stage + sizeof(double2) * FFT_TABLE_MAX);
+        for (size_t k = 0; k < entries; ++k) h[k] = make_float2((float)t[2 * k], (float)t[2 * k + 1]);
+        bytes = sizeof(float2) * entries;
+        src = h;
     } else {
-        double2* h = (double2*)c->na_stage;
-        for (int k = 0; k < n; ++k) {
-            const double a = -2.0 * M_PI * (double)k / (double)n;
-            h[k] = make_double2(cos(a), sin(a));
-        }
-        bytes = sizeof(double2) * (size_t)n;
+        bytes = sizeof(double2) * entries;
     }
     c->na_tw_n[which] = 0;
-    HIPCHK(c, hipMemcpyAsync(c->na_base + off[which], c->na_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->na_base + off[which], src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging is reused by the next table
     c->na_tw_n[which] = n;
     return STX_OK;
@@ -943,7 +953,7 @@ size_t na_carve(stx_ctx* c, const Prepared& pr, int F) {
     for (int i = 0; i < CB_COUNT; ++i) take(*chunk_buf(c->na, i), need[i]);
     if (pr.p.fft_exact >= 0) {
         size_t sb, cb, pb;
-        fft64_sizes(pr.g, &sb, &cb, &pb);
+        fft64_sizes(pr.g, pr.plan_w, pr.plan_h, &sb, &cb, &pb);
         take(c->spec64, sb);
         take(c->scratch64, cb);
         take(c->part64, pb);
@@ -986,7 +996,7 @@ int stx_analyze_batch_device_noalloc(stx_ctx* c, const uint8_t* bgr_dev, int n_f
                                           "(gray plane, edge maps, half spectrum and, unless fft_exact is -1, one fp64 "
                                           "spectrum must fit 128 MiB)");
     }
-    if ((rc = na_twiddles(c, 0, pr.g.fw)) == STX_OK) rc = na_twiddles(c, 1, pr.g.fh);
+    if ((rc = na_twiddles(c, 0, pr.plan_w)) == STX_OK) rc = na_twiddles(c, 1, pr.plan_h);
     pr.tw_w = (float2*)(c->na_base + NA_TW_W);
     pr.tw_h = (float2*)(c->na_base + NA_TW_H);
     for (int f0 = 0; f0 < n_frames && rc == STX_OK; f0 += chunk) {

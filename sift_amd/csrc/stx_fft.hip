@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(FftRowsArgs a) {
     extern __shared__ float2 lds[];
     const int n = a.fw, nb = a.nb, tid = threadIdx.x;
     cf* buf0 = reinterpret_cast<cf*>(lds);
-    cf* buf1 = buf0 + nb * n;
+    cf* buf1 = buf0 + nb * n;  // unused by the chirp-z transform (nb = 1, one buffer of bz_m elements)
     const int frame = blockIdx.y;
     const int row0 = blockIdx.x * 2 * nb;
     const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(FftRowsArgs a) {
         }
     }
     __syncthreads();
-    const cf* z = fft_run<float>(buf0, buf1, a.plan, nb, reinterpret_cast<const cf*>(a.tw), tid, 256);
+    const cf* z = buf0;
+    if (a.plan.bz_m) fft_bluestein<float>(buf0, n, a.plan.bz_m, reinterpret_cast<const cf*>(a.tw), tid, 256);
+    else z = fft_run<float>(buf0, buf1, a.plan, nb, reinterpret_cast<const cf*>(a.tw), tid, 256);
     for (int b = 0; b < nb; ++b) {
         const int ra = row0 + 2 * b, rb = ra + 1;
         if (ra >= a.fh) break;
@@ -96,7 +98,9 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
         buf0[c * n + y] = cf{v.x, v.y};
     }
     __syncthreads();
-    const cf* f = fft_run<float>(buf0, buf1, a.plan, cb, reinterpret_cast<const cf*>(a.tw), tid, 256);
+    const cf* f = buf0;
+    if (a.plan.bz_m) fft_bluestein<float>(buf0, n, a.plan.bz_m, reinterpret_cast<const cf*>(a.tw), tid, 256);
+    else f = fft_run<float>(buf0, buf1, a.plan, cb, reinterpret_cast<const cf*>(a.tw), tid, 256);
     double s = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
     const float dc_fix = (float)a.gray0[(int64_t)frame * a.gstride] * (float)a.fh * (float)a.fw;
     for (int c = 0; c < cb; ++c) {
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
 bool make_fft_plan(int n, FftPlan* plan) {
     plan->n = n;
     plan->npass = 0;
+    plan->bz_m = 0;
     int r = n;
     auto push = [&](int f) {
         if (plan->npass >= FFT_MAX_PASSES) return false;
@@ -157,14 +162,82 @@ bool make_fft_plan(int n, FftPlan* plan) {
     for (int p = 7; (long)p * p <= r; p += 2)
         while (r % p == 0) { if (!push(p)) return false; r /= p; }
     if (r > 1 && !push(r)) return false;
+    int largest = 1;
+    for (int p = 0; p < plan->npass; ++p) largest = plan->radix[p] > largest ? plan->radix[p] : largest;
+    if (largest > FFT_BLUESTEIN_MIN_PRIME) {
+        int m = 1;
+        while (m < 2 * n - 1) m <<= 1;
+        plan->bz_m = m;
+    }
     return true;
+}
+
+// exp(-i pi (k^2 mod 2n) / n): the square is reduced in integers first, the angle stays small
+static void chirp_at(long long k, int n, double* re, double* im) {
+    const long long q = (k * k) % (2LL * n);
+    const double a = -M_PI * (double)q / (double)n;
+    *re = cos(a);
+    *im = sin(a);
+}
+
+void fft_fill_table(const FftPlan& p, double* out) {
+    const int n = p.n;
+    if (!p.bz_m) {
+        for (int k = 0; k < n; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n;
+            out[2 * k] = cos(a);
+            out[2 * k + 1] = sin(a);
+        }
+        return;
+    }
+    const int m = p.bz_m;
+    double* chirp = out;
+    double* twm = out + 2 * (size_t)n;
+    double* bhat = twm + m;  // m/2 complex entries before it
+    for (int k = 0; k < n; ++k) chirp_at(k, n, &chirp[2 * k], &chirp[2 * k + 1]);
+    for (int j = 0; j < m / 2; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)m;
+        twm[2 * j] = cos(a);
+        twm[2 * j + 1] = sin(a);
+    }
+    // the convolution kernel conj(c[j]) at j and m-j, transformed (decimation in frequency, as on the device, so the
+    // result is already in bit-reversed order) and divided by m
+    std::vector<double> b(2 * (size_t)m, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double re, im;
+        chirp_at(j, n, &re, &im);
+        b[2 * (size_t)j] = re;
+        b[2 * (size_t)j + 1] = -im;
+        if (j) {
+            b[2 * (size_t)(m - j)] = re;
+            b[2 * (size_t)(m - j) + 1] = -im;
+        }
+    }
+    for (int half = m >> 1, step = 1; half >= 1; half >>= 1, step <<= 1)
+        for (int bfly = 0; bfly < m / 2; ++bfly) {
+            const int i = bfly & (half - 1);
+            const size_t lo = (size_t)((bfly - i) << 1) + i, hi = lo + half;
+            const double ur = b[2 * lo], ui = b[2 * lo + 1], vr = b[2 * hi], vi = b[2 * hi + 1];
+            const double wr = twm[2 * (size_t)(i * step)], wi = twm[2 * (size_t)(i * step) + 1];
+            b[2 * lo] = ur + vr;
+            b[2 * lo + 1] = ui + vi;
+            const double dr = ur - vr, di = ui - vi;
+            b[2 * hi] = dr * wr - di * wi;
+            b[2 * hi + 1] = dr * wi + di * wr;
+        }
+    for (size_t j = 0; j < 2 * (size_t)m; ++j) bhat[j] = b[j] / (double)m;
 }
 
 constexpr int FFT_LDS_BUDGET = 64 * 1024;
 constexpr int FFT_LDS_MAX = 159 * 1024;  // dynamic part; 1 KiB of the CU's 160 KiB is left for static LDS
 
 // LDS bytes for the generic row kernel and the number of row pairs per workgroup
-static int fft_lds_bytes_rows(int n, int* nb_out) {
+static int fft_lds_bytes_rows(const FftPlan& plan, int* nb_out) {
+    const int n = plan.n;
+    if (plan.bz_m) {  // one transform per workgroup in one buffer of the convolution length
+        *nb_out = 1;
+        return plan.bz_m * (int)sizeof(float2);
+    }
     int nb = FFT_LDS_BUDGET / (2 * n * (int)sizeof(float2));
     if (nb < 1) nb = 1;
     if (nb > 8) nb = 8;
@@ -174,13 +247,15 @@ static int fft_lds_bytes_rows(int n, int* nb_out) {
 
 // Spectrum layout [frame][nkb][fh][cbw]: blocks of cbw adjacent columns, each block contiguous,
 // so the column pass streams its input.  cbw is set by what the column kernel can hold in LDS.
-FftLayout fft_choose_layout(const Geom& g) {
+FftLayout fft_choose_layout(const Geom& g, const FftPlan& plan_h) {
     FftLayout l;
     l.fast_rows = fft_fast_available(g.fw);
     l.fast_cols = fft_fast_available(g.fh);
     int cbw;
     if (l.fast_cols) {
         cbw = fft_fast_cbw(g.fh);
+    } else if (plan_h.bz_m) {
+        cbw = 1;  // the chirp-z transform takes the workgroup's whole buffer for one column
     } else {
         cbw = FFT_LDS_MAX / (2 * g.fh * (int)sizeof(float2));
         if (cbw > 8) cbw = 8;
@@ -201,7 +276,7 @@ void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
     a.foy = g.foy; a.fox = g.fox; a.fh = g.fh; a.fw = g.fw; a.fwh = g.fwh;
     a.cbw = lay.cbw; a.nkb = lay.nkb;
     int nb;
-    const int lds = fft_lds_bytes_rows(g.fw, &nb);
+    const int lds = fft_lds_bytes_rows(plan, &nb);
     a.nb = nb; a.plan = plan; a.tw = tw; a.spec = spec;
     dim3 grid((g.fh + 2 * nb - 1) / (2 * nb), n_frames);
     hipLaunchKernelGGL(fft_rows_kernel, grid, dim3(256), lds, s, a);
@@ -218,7 +293,7 @@ void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int
     a.nblocks = lay.nkb;
     a.plan = plan; a.tw = tw; a.part = part; a.small = small;
     a.gray0 = gray0; a.gstride = gstride;
-    const int lds = 2 * a.cb * g.fh * (int)sizeof(float2);
+    const int lds = plan.bz_m ? plan.bz_m * (int)sizeof(float2) : 2 * a.cb * g.fh * (int)sizeof(float2);
     dim3 grid(a.nblocks, n_frames);
     hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(256), lds, s, a);
 }
@@ -238,6 +313,11 @@ hipError_t fft_set_lds_limits() {
 // Rounding noise of the fp32 transform: every butterfly stage adds a relative 2^-24 or so of the running values,
 // whose root-mean-square over the bins is sqrt(sum x^2) <= 255 sqrt(N) (Parseval); 3e-7 leaves room for the
 // log2(N)/2 stages' accumulation and the twiddle errors.
-double fft_f32_bin_error(int fh, int fw) { return 3e-7 * 255.0 * sqrt((double)fh * (double)fw); }
+// A chirp-z dimension goes through two transforms four times its length and three products: four times the noise.
+double fft_f32_bin_error(int fh, int fw) {
+    FftPlan ph, pw;
+    const bool bz = (make_fft_plan(fh, &ph) && ph.bz_m) || (make_fft_plan(fw, &pw) && pw.bz_m);
+    return (bz ? 4.0 : 1.0) * 3e-7 * 255.0 * sqrt((double)fh * (double)fw);
+}
 
 }  // namespace stx

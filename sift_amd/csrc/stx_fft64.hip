@@ -15,14 +15,26 @@ typedef Cpx<double> cd;
 
 constexpr int F64_THREADS = 256;
 constexpr int F64_LDS_MAX = 156 * 1024;  // dynamic LDS a workgroup may take (the rest is left for static LDS)
+constexpr int F64_MAX_GRID = 512;        // workgroups per launch: each walks over its transforms, and owns one scratch slice
 
-// One transform per workgroup.  Both pass buffers live in LDS when they fit (n <= 4992); longer transforms keep the
-// first in LDS and the second in a per-workgroup slice of global scratch.
-static size_t f64_lds_bytes(int n) {
-    const size_t two = 2 * (size_t)n * sizeof(cd);
-    return two <= (size_t)F64_LDS_MAX ? two : (size_t)n * sizeof(cd);
+// One transform at a time per workgroup.  Both pass buffers live in LDS when they fit (n <= 4992); longer transforms
+// keep the first in LDS and the second in the workgroup's slice of global scratch.  The chirp-z transform of a length
+// with a large prime factor works in one buffer of its convolution length: in LDS up to 8192 elements, else in the
+// scratch slice.
+static size_t f64_lds_bytes(const FftPlan& p) {
+    if (p.bz_m) {
+        const size_t one = (size_t)p.bz_m * sizeof(cd);
+        return one <= (size_t)F64_LDS_MAX ? one : 0;
+    }
+    const size_t two = 2 * (size_t)p.n * sizeof(cd);
+    return two <= (size_t)F64_LDS_MAX ? two : (size_t)p.n * sizeof(cd);
 }
-static bool f64_needs_scratch(int n) { return 2 * (size_t)n * sizeof(cd) > (size_t)F64_LDS_MAX; }
+// elements of global scratch per workgroup
+static size_t f64_scratch_elems(const FftPlan& p) {
+    if (p.bz_m) return (size_t)p.bz_m * sizeof(cd) <= (size_t)F64_LDS_MAX ? 0 : (size_t)p.bz_m;
+    return 2 * (size_t)p.n * sizeof(cd) > (size_t)F64_LDS_MAX ? (size_t)p.n : 0;
+}
+static int f64_grid(int units) { return units < F64_MAX_GRID ? units : F64_MAX_GRID; }
 
 struct Rows64Args {
     const uint8_t* gray;  // padded plane of one frame
@@ -31,27 +43,36 @@ struct Rows64Args {
     FftPlan plan;
     const cd* tw;
     cd* spec;     // [fh][fwh]
-    cd* scratch;  // [workgroups][fw] or null
+    cd* scratch;  // [workgroups][scratch_elems] or null
+    int scratch_elems;
 };
 
 __global__ __launch_bounds__(F64_THREADS) void fft64_rows_kernel(Rows64Args a) {
     extern __shared__ double2 lds64[];
     const int n = a.fw, tid = threadIdx.x;
-    cd* buf0 = reinterpret_cast<cd*>(lds64);
-    cd* buf1 = a.scratch ? a.scratch + (int64_t)blockIdx.x * n : buf0 + n;
-    const int ra = 2 * blockIdx.x, rb = ra + 1;
+    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
+    const bool bz = a.plan.bz_m != 0;
+    // chirp-z: the one work buffer, in LDS or (too long for it) in the scratch slice
+    cd* buf0 = (bz && slice) ? slice : reinterpret_cast<cd*>(lds64);
+    cd* buf1 = slice ? slice : buf0 + n;
     const double m = (double)a.gray[(int64_t)(a.foy + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF];
-    const uint8_t* pa = a.gray + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
-    const uint8_t* pb = pa + a.gpitch;
-    for (int x = tid; x < n; x += F64_THREADS)
-        buf0[x] = cd{(double)pa[x] - m, rb < a.fh ? (double)pb[x] - m : 0.0};
-    __syncthreads();
-    const cd* z = fft_run<double>(buf0, buf1, a.plan, 1, a.tw, tid, F64_THREADS);
-    // rows ra and rb from the packed transform: A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i
-    for (int k = tid; k < a.fwh; k += F64_THREADS) {
-        const cd zk = z[k], zc = z[k ? n - k : 0];
-        a.spec[(int64_t)ra * a.fwh + k] = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y)};
-        if (rb < a.fh) a.spec[(int64_t)rb * a.fwh + k] = cd{0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x)};
+    for (int unit = blockIdx.x; 2 * unit < a.fh; unit += gridDim.x) {
+        const int ra = 2 * unit, rb = ra + 1;
+        const uint8_t* pa = a.gray + (int64_t)(a.foy + ra + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF;
+        const uint8_t* pb = pa + a.gpitch;
+        for (int x = tid; x < n; x += F64_THREADS)
+            buf0[x] = cd{(double)pa[x] - m, rb < a.fh ? (double)pb[x] - m : 0.0};
+        __syncthreads();
+        const cd* z = buf0;
+        if (bz) fft_bluestein<double>(buf0, n, a.plan.bz_m, a.tw, tid, F64_THREADS);
+        else z = fft_run<double>(buf0, buf1, a.plan, 1, a.tw, tid, F64_THREADS);
+        // rows ra and rb from the packed transform: A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i
+        for (int k = tid; k < a.fwh; k += F64_THREADS) {
+            const cd zk = z[k], zc = z[k ? n - k : 0];
+            a.spec[(int64_t)ra * a.fwh + k] = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y)};
+            if (rb < a.fh) a.spec[(int64_t)rb * a.fwh + k] = cd{0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x)};
+        }
+        __syncthreads();  // the next signal overwrites what other threads have just read
     }
 }
 
@@ -61,6 +82,7 @@ struct Cols64Args {
     FftPlan plan;
     const cd* tw;
     cd* scratch;
+    int scratch_elems;
     double2* part;  // [fwh] (sum, sum of squares) of ln(|F|+1), weighted twice where the column has a mirror image
     const uint8_t* gray0;  // first pixel of the transformed region: its level times fh*fw goes back into bin (0,0)
 };
@@ -68,38 +90,46 @@ struct Cols64Args {
 __global__ __launch_bounds__(F64_THREADS) void fft64_cols_kernel(Cols64Args a) {
     extern __shared__ double2 lds64[];
     __shared__ double red[2][F64_THREADS / 64];
-    const int n = a.fh, tid = threadIdx.x, k = blockIdx.x;
-    cd* buf0 = reinterpret_cast<cd*>(lds64);
-    cd* buf1 = a.scratch ? a.scratch + (int64_t)k * n : buf0 + n;
-    for (int y = tid; y < n; y += F64_THREADS) buf0[y] = a.spec[(int64_t)y * a.fwh + k];
-    __syncthreads();
-    const cd* f = fft_run<double>(buf0, buf1, a.plan, 1, a.tw, tid, F64_THREADS);
-    double s = 0.0, s2 = 0.0;
-    for (int y = tid; y < n; y += F64_THREADS) {
-        cd v = f[y];
-        if (k == 0 && y == 0) v.x += (double)*a.gray0 * (double)a.fh * (double)a.fw;
-        const double l = log(sqrt(v.x * v.x + v.y * v.y) + 1.0);
-        s += l;
-        s2 += l * l;
-    }
+    const int n = a.fh, tid = threadIdx.x;
+    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
+    const bool bz = a.plan.bz_m != 0;
+    cd* buf0 = (bz && slice) ? slice : reinterpret_cast<cd*>(lds64);
+    cd* buf1 = slice ? slice : buf0 + n;
+    for (int k = blockIdx.x; k < a.fwh; k += gridDim.x) {
+        for (int y = tid; y < n; y += F64_THREADS) buf0[y] = a.spec[(int64_t)y * a.fwh + k];
+        __syncthreads();
+        const cd* f = buf0;
+        if (bz) fft_bluestein<double>(buf0, n, a.plan.bz_m, a.tw, tid, F64_THREADS);
+        else f = fft_run<double>(buf0, buf1, a.plan, 1, a.tw, tid, F64_THREADS);
+        double s = 0.0, s2 = 0.0;
+        for (int y = tid; y < n; y += F64_THREADS) {
+            cd v = f[y];
+            if (k == 0 && y == 0) v.x += (double)*a.gray0 * (double)a.fh * (double)a.fw;
+            const double l = log(sqrt(v.x * v.x + v.y * v.y) + 1.0);
+            s += l;
+            s2 += l * l;
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = s2; }
-    __syncthreads();
-    if (tid == 0) {
-        const double wgt = (k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0;
-        a.part[k] = make_double2(wgt * (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]),
-                                 wgt * (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            const double wgt = (k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0;
+            a.part[k] = make_double2(wgt * (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]),
+                                     wgt * (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
+        }
+        __syncthreads();  // the next column overwrites the buffers and the partial sums
     }
 }
 
-void fft64_sizes(const Geom& g, size_t* spec_bytes, size_t* scratch_bytes, size_t* part_bytes) {
+void fft64_sizes(const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h, size_t* spec_bytes, size_t* scratch_bytes,
+                 size_t* part_bytes) {
     *spec_bytes = (size_t)g.fh * g.fwh * sizeof(cd);
-    const size_t rows = f64_needs_scratch(g.fw) ? (size_t)((g.fh + 1) / 2) * g.fw * sizeof(cd) : 0;
-    const size_t cols = f64_needs_scratch(g.fh) ? (size_t)g.fwh * g.fh * sizeof(cd) : 0;
+    const size_t rows = f64_scratch_elems(plan_w) * (size_t)f64_grid((g.fh + 1) / 2) * sizeof(cd);
+    const size_t cols = f64_scratch_elems(plan_h) * (size_t)f64_grid(g.fwh) * sizeof(cd);
     *scratch_bytes = rows > cols ? rows : cols;
     *part_bytes = (size_t)g.fwh * sizeof(double2);
 }
@@ -110,15 +140,17 @@ void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const
     r.gray = gray_frame; r.gpitch = g.gpitch;
     r.foy = g.foy; r.fox = g.fox; r.fh = g.fh; r.fw = g.fw; r.fwh = g.fwh;
     r.plan = plan_w; r.tw = (const cd*)tw_w; r.spec = (cd*)w.spec;
-    r.scratch = f64_needs_scratch(g.fw) ? (cd*)w.scratch : nullptr;
-    hipLaunchKernelGGL(fft64_rows_kernel, dim3((g.fh + 1) / 2), dim3(F64_THREADS), f64_lds_bytes(g.fw), s, r);
+    r.scratch_elems = (int)f64_scratch_elems(plan_w);
+    r.scratch = r.scratch_elems ? (cd*)w.scratch : nullptr;
+    hipLaunchKernelGGL(fft64_rows_kernel, dim3(f64_grid((g.fh + 1) / 2)), dim3(F64_THREADS), f64_lds_bytes(plan_w), s, r);
     Cols64Args c;
     c.spec = (const cd*)w.spec; c.fh = g.fh; c.fw = g.fw; c.fwh = g.fwh;
     c.plan = plan_h; c.tw = (const cd*)tw_h;
-    c.scratch = f64_needs_scratch(g.fh) ? (cd*)w.scratch : nullptr;
+    c.scratch_elems = (int)f64_scratch_elems(plan_h);
+    c.scratch = c.scratch_elems ? (cd*)w.scratch : nullptr;
     c.part = (double2*)w.part;
     c.gray0 = gray_frame + (int64_t)(g.foy + GRAY_YOFF) * g.gpitch + g.fox + GRAY_XOFF;
-    hipLaunchKernelGGL(fft64_cols_kernel, dim3(g.fwh), dim3(F64_THREADS), f64_lds_bytes(g.fh), s, c);
+    hipLaunchKernelGGL(fft64_cols_kernel, dim3(f64_grid(g.fwh)), dim3(F64_THREADS), f64_lds_bytes(plan_h), s, c);
 }
 
 hipError_t fft64_set_lds_limits() {

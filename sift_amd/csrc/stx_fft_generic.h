@@ -116,6 +116,50 @@ __device__ void fft_pass(const Cpx<T>* __restrict__ in, Cpx<T>* __restrict__ out
     }
 }
 
+// Chirp-z (Bluestein) transform of one signal of any length n, in place, for lengths with a large prime factor
+// (a direct DFT pass costs n times that factor).  With c[k] = exp(-i pi k^2 / n),
+//     X[k] = c[k] * sum_j (x[j] c[j]) conj(c[k-j]):
+// a circular convolution of length m (a power of two, >= 2n-1) with a fixed kernel, done as forward transform,
+// product with the kernel's transform, inverse transform.  The forward transform is decimation in frequency
+// (natural order in, bit-reversed out), the inverse decimation in time (bit-reversed in, natural out), and the
+// kernel's transform is tabulated in bit-reversed order: no reordering pass, one buffer of m elements.
+// work[0..n) holds x on entry and X on return (work[n..m) is scratch); LDS or global memory, one workgroup.
+// tab: [n] c, then [m/2] exp(-2 pi i j / m), then [m] transform of the kernel / m, bit-reversed.
+template <class T>
+__device__ void fft_bluestein(Cpx<T>* work, int n, int m, const Cpx<T>* __restrict__ tab, int tid, int nthreads) {
+    typedef Cpx<T> C;
+    const C* chirp = tab;
+    const C* twm = tab + n;
+    const C* bhat = twm + m / 2;
+    for (int j = tid; j < m; j += nthreads) work[j] = j < n ? cmul(work[j], chirp[j]) : mk<T>(0, 0);
+    __syncthreads();
+    for (int half = m >> 1, step = 1; half >= 1; half >>= 1, step <<= 1) {
+        for (int b = tid; b < m / 2; b += nthreads) {
+            const int i = b & (half - 1);
+            const int lo = ((b - i) << 1) + i, hi = lo + half;
+            const C u = work[lo], v = work[hi];
+            work[lo] = cadd(u, v);
+            work[hi] = cmul(csub(u, v), twm[i * step]);
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < m; j += nthreads) work[j] = cmul(work[j], bhat[j]);
+    __syncthreads();
+    for (int half = 1, step = m >> 1; half < m; half <<= 1, step >>= 1) {
+        for (int b = tid; b < m / 2; b += nthreads) {
+            const int i = b & (half - 1);
+            const int lo = ((b - i) << 1) + i, hi = lo + half;
+            const C w = twm[i * step];
+            const C u = work[lo], v = cmul(work[hi], mk<T>(w.x, -w.y));
+            work[lo] = cadd(u, v);
+            work[hi] = csub(u, v);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += nthreads) work[k] = cmul(work[k], chirp[k]);
+    __syncthreads();
+}
+
 // runs the whole plan; returns the buffer that holds the result
 template <class T>
 __device__ Cpx<T>* fft_run(Cpx<T>* a, Cpx<T>* b, const FftPlan& plan, int nb, const Cpx<T>* tw, int tid, int nthreads) {

@@ -66,7 +66,17 @@ struct FftPlan {
     int n;
     int npass;
     int radix[FFT_MAX_PASSES];
+    // 0, or the convolution length of the chirp-z transform that lengths with a prime factor above
+    // FFT_BLUESTEIN_MIN_PRIME take instead of the passes (their table is fft_table_entries(plan) long, see
+    // fft_fill_table)
+    int bz_m;
 };
+constexpr int FFT_BLUESTEIN_MIN_PRIME = 256;
+// Entries of the table a plan's kernels read: n twiddles exp(-2 pi i k / n), or the three chirp-z tables.
+inline size_t fft_table_entries(const FftPlan& p) { return p.bz_m ? (size_t)p.n + (size_t)p.bz_m / 2 + (size_t)p.bz_m : (size_t)p.n; }
+constexpr size_t FFT_TABLE_MAX = (size_t)STX_MAX_DIM + (size_t)STX_MAX_DIM + 2 * (size_t)STX_MAX_DIM;  // n <= STX_MAX_DIM, m <= 2 STX_MAX_DIM
+// Fills a plan's table in double precision (re, im interleaved).
+void fft_fill_table(const FftPlan& p, double* out);
 
 // Partial sums of one spectrum column (weighted twice where the column stands for its mirror image too).
 // l = ln(|F|+1).  t1, t2 cover only the bins with |F| < the `small` threshold of the launch: those are the bins
@@ -119,7 +129,7 @@ struct FftLayout {
     int parts_per_frame;
     bool fast_rows, fast_cols;
 };
-FftLayout fft_choose_layout(const Geom& g);
+FftLayout fft_choose_layout(const Geom& g, const FftPlan& plan_h);
 void launch_fft_rows(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const FftLayout& lay,
                      const FftPlan& plan, const float2* tw, float2* spec);
 void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int n_frames, const Geom& g,
@@ -137,7 +147,8 @@ struct Fft64Work {
     void* part = nullptr;     // [fwh] double2 (sum, sum of squares) per column, weighted
     size_t spec_bytes = 0, scratch_bytes = 0, part_bytes = 0;
 };
-void fft64_sizes(const Geom& g, size_t* spec_bytes, size_t* scratch_bytes, size_t* part_bytes);
+void fft64_sizes(const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h, size_t* spec_bytes, size_t* scratch_bytes,
+                 size_t* part_bytes);
 // gray_frame: the padded gray plane of ONE frame; tw_w / tw_h: double2 tables exp(-2 pi i k / n) of fw / fh entries
 void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h,
                   const void* tw_w, const void* tw_h, const Fft64Work& w);

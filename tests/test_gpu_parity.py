@@ -201,6 +201,19 @@ def test_odd_fft_sizes(ctx, coracle):
         _check_record(ctx.analyze_frames([f])[0], coracle.analyze_frame(f))
 
 
+@pytest.mark.parametrize("h,w", [(521, 66), (66, 523), (521, 523), (2 * 263, 3 * 257), (4099, 64), (48, 4099), (1, 263), (263, 1)])
+def test_sizes_with_large_prime_factors(ctx, coracle, h, w):
+    # lengths with a prime factor above 256 take the chirp-z transform (m = 1024 .. 16384), in fp32 and in fp64
+    f = synth_frame("noise", SEED, 33, 0, h, w)
+    ref = _np_freq(coracle.gray(f))
+    assert ctx.analyze_frames([f])[0].frequency_anomaly == pytest.approx(ref, rel=REL, abs=1e-9)
+    p = ctx.default_params(); p.fft_exact = 1
+    assert ctx.analyze_frames([f], p)[0].frequency_anomaly == pytest.approx(ref, rel=1e-9, abs=1e-12)
+    if h * w < 100000:
+        g = synth_frame("ramp", SEED, 33, 0, h, w)  # near-zero bins: the fp64 re-transform must kick in by itself
+        assert ctx.analyze_frames([g])[0].frequency_anomaly == pytest.approx(_np_freq(coracle.gray(g)), rel=REL, abs=1e-9)
+
+
 def test_long_contours_hysteresis(ctx, coracle):
     # weak contours hundreds of pixels long hanging off a single strong seed: many
     # tile-to-tile propagation passes

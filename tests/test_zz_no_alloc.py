@@ -42,7 +42,9 @@ def test_noalloc_matches_allocating_entry_point_twice():
         # first call: more frames than one pass over the scratch array takes at this size, camera-like and
         # structured content (the second goes through the fp64 transform); second call: fewer, smaller frames
         for (n, h, w, kind) in ((70, 270, 480, "natural"), (5, 1080, 1920, "natural"), (3, 200, 328, "ramp"),
-                                (2, 96, 160, "noise")):
+                                (2, 96, 160, "noise"),
+                                # lengths with a large prime factor: the chirp-z tables go through the scratch array too
+                                (2, 263, 523, "noise"), (1, 263, 523, "ramp")):
             dev = ctx.device_alloc(n * h * w * 3)
             try:
                 ctx.synth_device(dev, KIND_ID[kind], 0x5EED0009, 1, 0, n, h, w)
