@@ -630,9 +630,10 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
     int rc;
     void *tw_w = nullptr, *tw_h = nullptr;
     double2* part_host;
+    int batch;  // frames per launch: as many as the workspace holds, at most FFT64_BATCH
     if (sl.gray.fixed) {
-        // allocation-free path: the workspace was carved from the scratch array with the chunk's buffers, the
-        // twiddle tables have their own places in it, the column sums come back through the pinned staging
+        // allocation-free path: the workspace was carved from the scratch array with the chunk's buffers (one
+        // frame's worth), the tables have their own places in it, the column sums come back through the pinned staging
         w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
         if (c->spec64.cap < w.spec_bytes || c->scratch64.cap < w.scratch_bytes || c->part64.cap < w.part_bytes)
             return fail(c, STX_ERR_NOMEM, "internal: fp64 workspace of the allocation-free path is too small");
@@ -640,32 +641,38 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
         tw_w = c->na_base + NA_TW64_W;
         tw_h = c->na_base + NA_TW64_H;
         part_host = (double2*)c->na_stage;
+        batch = 1;
     } else {
-        if ((rc = ensure(c, c->spec64, w.spec_bytes)) != STX_OK) return rc;
-        if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes)) != STX_OK) return rc;
-        if ((rc = ensure(c, c->part64, w.part_bytes)) != STX_OK) return rc;
+        const size_t per_frame = w.spec_bytes + w.scratch_bytes + w.part_bytes;
+        batch = (int)std::min<size_t>((size_t)std::min(n_redo, FFT64_BATCH), std::max<size_t>(1, ((size_t)1 << 30) / per_frame));
+        if ((rc = ensure(c, c->spec64, w.spec_bytes * batch)) != STX_OK) return rc;
+        if (w.scratch_bytes && (rc = ensure(c, c->scratch64, w.scratch_bytes * batch)) != STX_OK) return rc;
+        if ((rc = ensure(c, c->part64, w.part_bytes * batch)) != STX_OK) return rc;
         w.spec = c->spec64.p; w.scratch = c->scratch64.p; w.part = c->part64.p;
         if ((rc = get_twiddles64(c, pr.plan_w, &tw_w)) != STX_OK) return rc;
         if ((rc = get_twiddles64(c, pr.plan_h, &tw_h)) != STX_OK) return rc;
         try {
-            c->part64_host.resize((size_t)g.fwh);
+            c->part64_host.resize((size_t)g.fwh * batch);
         } catch (const std::bad_alloc&) {
             return fail(c, STX_ERR_NOMEM, "out of host memory");
         }
         part_host = c->part64_host.data();
     }
-    for (int i = 0; i < n_redo; ++i) {
-        const int f = frames[i];
-        launch_fft64(c->stream, (const uint8_t*)sl.gray.p + (size_t)f * g.grows * g.gpitch, g, pr.plan_w, pr.plan_h, tw_w,
-                     tw_h, w);
-        HIPCHK(c, hipMemcpyAsync(part_host, w.part, w.part_bytes, hipMemcpyDeviceToHost, c->stream));
+    for (int i0 = 0; i0 < n_redo; i0 += batch) {
+        const int nb = std::min(batch, n_redo - i0);
+        launch_fft64(c->stream, (const uint8_t*)sl.gray.p, frames + i0, nb, g, pr.plan_w, pr.plan_h, tw_w, tw_h, w);
+        HIPCHK(c, hipMemcpyAsync(part_host, w.part, w.part_bytes * nb, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
-        double s = 0.0, s2 = 0.0;  // fixed order: reproducible
-        for (int k = 0; k < g.fwh; ++k) { s += part_host[k].x; s2 += part_host[k].y; }
-        sl.acc_host[f].fft_sum = s;
-        sl.acc_host[f].fft_sumsq = s2;
-        sl.acc_host[f].pad0 = 1u;
+        for (int b = 0; b < nb; ++b) {
+            const int f = frames[i0 + b];
+            const double2* ph = part_host + (size_t)b * g.fwh;
+            double s = 0.0, s2 = 0.0;  // fixed order: reproducible
+            for (int k = 0; k < g.fwh; ++k) { s += ph[k].x; s2 += ph[k].y; }
+            sl.acc_host[f].fft_sum = s;
+            sl.acc_host[f].fft_sumsq = s2;
+            sl.acc_host[f].pad0 = 1u;
+        }
     }
     c->fft64_frames += (uint64_t)n_redo;
     return STX_OK;

@@ -6,7 +6,7 @@
 // noise), but an image whose exact spectrum is zero in many bins (ramps, step edges, flat synthetic content) gets
 // ln(1 + noise) there instead of 0.  The host decides per frame from the sums the fp32 column pass leaves
 // (FftPart::t1, t2) and sends such frames through these kernels: same structure as the generic fp32 pair
-// (row pairs packed into one complex transform, then columns), one frame per launch, any size.
+// (row pairs packed into one complex transform, then columns), up to FFT64_BATCH frames per launch, any size.
 #include "stx_fft_generic.h"
 
 namespace stx {
@@ -37,7 +37,10 @@ static size_t f64_scratch_elems(const FftPlan& p) {
 static int f64_grid(int units) { return units < F64_MAX_GRID ? units : F64_MAX_GRID; }
 
 struct Rows64Args {
-    const uint8_t* gray;  // padded plane of one frame
+    const uint8_t* gray;  // padded planes of the chunk
+    int64_t gstride;      // bytes from one frame's plane to the next
+    int frames[FFT64_BATCH];  // blockIdx.y -> frame of the chunk
+    int64_t spec_stride, scratch_stride;  // elements from one batch slot to the next
     int gpitch;
     int foy, fox, fh, fw, fwh;
     FftPlan plan;
@@ -50,11 +53,13 @@ struct Rows64Args {
 __global__ __launch_bounds__(F64_THREADS) void fft64_rows_kernel(Rows64Args a) {
     extern __shared__ double2 lds64[];
     const int n = a.fw, tid = threadIdx.x;
-    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
+    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.y * a.scratch_stride + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
     const bool bz = a.plan.bz_m != 0;
     // chirp-z: the one work buffer, in LDS or (too long for it) in the scratch slice
     cd* buf0 = (bz && slice) ? slice : reinterpret_cast<cd*>(lds64);
     cd* buf1 = slice ? slice : buf0 + n;
+    a.gray += (int64_t)a.frames[blockIdx.y] * a.gstride;
+    a.spec += (int64_t)blockIdx.y * a.spec_stride;
     const double m = (double)a.gray[(int64_t)(a.foy + GRAY_YOFF) * a.gpitch + a.fox + GRAY_XOFF];
     for (int unit = blockIdx.x; 2 * unit < a.fh; unit += gridDim.x) {
         const int ra = 2 * unit, rb = ra + 1;
@@ -77,6 +82,8 @@ __global__ __launch_bounds__(F64_THREADS) void fft64_rows_kernel(Rows64Args a) {
 }
 
 struct Cols64Args {
+    int64_t spec_stride, scratch_stride, part_stride, gray0_stride;  // from one batch slot (frame, for gray0) to the next
+    int frames[FFT64_BATCH];
     const cd* spec;
     int fh, fw, fwh;
     FftPlan plan;
@@ -91,10 +98,13 @@ __global__ __launch_bounds__(F64_THREADS) void fft64_cols_kernel(Cols64Args a) {
     extern __shared__ double2 lds64[];
     __shared__ double red[2][F64_THREADS / 64];
     const int n = a.fh, tid = threadIdx.x;
-    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
+    cd* slice = a.scratch ? a.scratch + (int64_t)blockIdx.y * a.scratch_stride + (int64_t)blockIdx.x * a.scratch_elems : nullptr;
     const bool bz = a.plan.bz_m != 0;
     cd* buf0 = (bz && slice) ? slice : reinterpret_cast<cd*>(lds64);
     cd* buf1 = slice ? slice : buf0 + n;
+    a.spec += (int64_t)blockIdx.y * a.spec_stride;
+    a.part += (int64_t)blockIdx.y * a.part_stride;
+    a.gray0 += (int64_t)a.frames[blockIdx.y] * a.gray0_stride;
     for (int k = blockIdx.x; k < a.fwh; k += gridDim.x) {
         for (int y = tid; y < n; y += F64_THREADS) buf0[y] = a.spec[(int64_t)y * a.fwh + k];
         __syncthreads();
@@ -134,23 +144,30 @@ void fft64_sizes(const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h, si
     *part_bytes = (size_t)g.fwh * sizeof(double2);
 }
 
-void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h,
-                  const void* tw_w, const void* tw_h, const Fft64Work& w) {
+void launch_fft64(hipStream_t s, const uint8_t* gray_chunk, const int* frames, int n_batch, const Geom& g,
+                  const FftPlan& plan_w, const FftPlan& plan_h, const void* tw_w, const void* tw_h, const Fft64Work& w) {
+    const int64_t spec_stride = (int64_t)(w.spec_bytes / sizeof(cd));
+    const int64_t scratch_stride = (int64_t)(w.scratch_bytes / sizeof(cd));
     Rows64Args r;
-    r.gray = gray_frame; r.gpitch = g.gpitch;
+    r.gray = gray_chunk; r.gstride = (int64_t)g.grows * g.gpitch; r.gpitch = g.gpitch;
+    r.spec_stride = spec_stride; r.scratch_stride = scratch_stride;
     r.foy = g.foy; r.fox = g.fox; r.fh = g.fh; r.fw = g.fw; r.fwh = g.fwh;
     r.plan = plan_w; r.tw = (const cd*)tw_w; r.spec = (cd*)w.spec;
     r.scratch_elems = (int)f64_scratch_elems(plan_w);
     r.scratch = r.scratch_elems ? (cd*)w.scratch : nullptr;
-    hipLaunchKernelGGL(fft64_rows_kernel, dim3(f64_grid((g.fh + 1) / 2)), dim3(F64_THREADS), f64_lds_bytes(plan_w), s, r);
     Cols64Args c;
+    c.spec_stride = spec_stride; c.scratch_stride = scratch_stride;
+    c.part_stride = (int64_t)(w.part_bytes / sizeof(double2));
+    c.gray0_stride = r.gstride;
+    for (int i = 0; i < FFT64_BATCH; ++i) r.frames[i] = c.frames[i] = i < n_batch ? frames[i] : 0;
+    hipLaunchKernelGGL(fft64_rows_kernel, dim3(f64_grid((g.fh + 1) / 2), n_batch), dim3(F64_THREADS), f64_lds_bytes(plan_w), s, r);
     c.spec = (const cd*)w.spec; c.fh = g.fh; c.fw = g.fw; c.fwh = g.fwh;
     c.plan = plan_h; c.tw = (const cd*)tw_h;
     c.scratch_elems = (int)f64_scratch_elems(plan_h);
     c.scratch = c.scratch_elems ? (cd*)w.scratch : nullptr;
     c.part = (double2*)w.part;
-    c.gray0 = gray_frame + (int64_t)(g.foy + GRAY_YOFF) * g.gpitch + g.fox + GRAY_XOFF;
-    hipLaunchKernelGGL(fft64_cols_kernel, dim3(f64_grid(g.fwh)), dim3(F64_THREADS), f64_lds_bytes(plan_h), s, c);
+    c.gray0 = gray_chunk + (int64_t)(g.foy + GRAY_YOFF) * g.gpitch + g.fox + GRAY_XOFF;
+    hipLaunchKernelGGL(fft64_cols_kernel, dim3(f64_grid(g.fwh), n_batch), dim3(F64_THREADS), f64_lds_bytes(plan_h), s, c);
 }
 
 hipError_t fft64_set_lds_limits() {

@@ -149,9 +149,11 @@ struct Fft64Work {
 };
 void fft64_sizes(const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h, size_t* spec_bytes, size_t* scratch_bytes,
                  size_t* part_bytes);
-// gray_frame: the padded gray plane of ONE frame; tw_w / tw_h: double2 tables exp(-2 pi i k / n) of fw / fh entries
-void launch_fft64(hipStream_t s, const uint8_t* gray_frame, const Geom& g, const FftPlan& plan_w, const FftPlan& plan_h,
-                  const void* tw_w, const void* tw_h, const Fft64Work& w);
+// gray_chunk: the padded gray planes of the chunk, frames[0..n_batch) the ones to transform; tw_w / tw_h: the plans' double2 tables
+// spec / scratch / part hold one slot of spec_bytes / scratch_bytes / part_bytes per frame of the batch
+constexpr int FFT64_BATCH = 32;
+void launch_fft64(hipStream_t s, const uint8_t* gray_chunk, const int* frames, int n_batch, const Geom& g,
+                  const FftPlan& plan_w, const FftPlan& plan_h, const void* tw_w, const void* tw_h, const Fft64Work& w);
 hipError_t fft64_set_lds_limits();
 // compile-time-planned kernels for the common sizes (stx_fft_fast.hip)
 bool fft_fast_available(int n);
