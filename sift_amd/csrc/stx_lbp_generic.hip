@@ -43,22 +43,49 @@ struct LbpGenArgs {
 // (low half = the pixel, high half = the next one): a cell row is then one aligned 32-bit read and one
 // v_dot2_u32_u16 with the row's two weights.  PT > 0 unrolls the sample loop for that P (the per-sample
 // constants become scalar registers loaded in batches); PT == 0 is the loop for any other P.
+//
+// RING: the cell positions of (P=16, R=2) and (P=24, R=3) -- the two extra radii of the extended analysis -- are
+// compile-time tables, so a cell row's LDS address is the pixel's base register plus an immediate offset (two
+// address additions less per sample, a fifth of the instructions of the sample loop).
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t b, uint32_t acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), acc, false);
 }
 
+// floor of the row / column offset of sample p, and whether the cell has a second row / column
+constexpr int RING16_FR[16] = {0, -1, -2, -2, -2, -2, -2, -1, 0, 0, 1, 1, 2, 1, 1, 0};
+constexpr int RING16_FC[16] = {2, 1, 1, 0, 0, -1, -2, -2, -2, -2, -2, -1, 0, 0, 1, 1};
+constexpr int RING16_D1[16] = {0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1};  // rows and columns alike
+constexpr int RING24_FR[24] = {0, -1, -2, -3, -3, -3, -3, -3, -3, -3, -2, -1, 0, 0, 1, 2, 2, 2, 3, 2, 2, 2, 1, 0};
+constexpr int RING24_FC[24] = {3, 2, 2, 2, 1, 0, 0, -1, -2, -3, -3, -3, -3, -3, -3, -3, -2, -1, 0, 0, 1, 2, 2, 2};
+constexpr int RING24_D1[24] = {0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1};
 template <int PT>
+struct Ring {
+    static constexpr int HALO = PT == 16 ? 2 : 3;
+    static constexpr int LPITCH = (GL_TILE + 2 * HALO) | 1;
+    static constexpr int fr(int p) { return PT == 16 ? RING16_FR[p] : RING24_FR[p]; }
+    static constexpr int fc(int p) { return PT == 16 ? RING16_FC[p] : RING24_FC[p]; }
+    static constexpr int d1(int p) { return PT == 16 ? RING16_D1[p] : RING24_D1[p]; }
+    // entry offsets relative to the entry HALO rows and HALO columns up and left of the centre (all >= 0)
+    static constexpr int top(int p) { return (fr(p) + HALO) * LPITCH + fc(p) + HALO; }
+    static constexpr int bot(int p) { return top(p) + d1(p) * LPITCH; }
+};
+
+constexpr int GL_QUEUE = 256;  // undecided pixels a wave can queue per strip of GL_ROWS rows
+
+template <int PT, bool RING>
 __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     extern __shared__ uint32_t gl_tile[];  // (GL_TILE + 2*halo) rows of lpitch pairs
     // Sixteen copies of the histogram, 33 words apart (a copy per bank offset): neighbouring pixels mostly
     // fall into the same bin, and 64 lanes adding to one LDS word would be served one after the other.
     __shared__ uint32_t hist[GL_COPIES * GL_HSTRIDE];
     __shared__ double offs[2][24];
+    // undecided pixels of each wave's strip: .x = sign bits | row << 24, .y = undecided samples | lane << 24
+    __shared__ uint2 queue[4][GL_QUEUE];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
     const int tid = threadIdx.x;
-    const int halo = a.halo, lpitch = a.lpitch;
+    const int halo = RING ? Ring<PT>::HALO : a.halo, lpitch = RING ? Ring<PT>::LPITCH : a.lpitch;
     const int trows = GL_TILE + 2 * halo;
 
     const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
@@ -77,63 +104,100 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     if (tid < 24) { offs[0][tid] = a.off.rp[tid]; offs[1][tid] = a.off.cp[tid]; }
     __syncthreads();
 
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = x0 + lane;
     const int P = PT > 0 ? PT : a.P;
     const uint32_t pmask = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u);
-    if (x < a.W) {
-        for (int i = 0; i < GL_ROWS; ++i) {
-            const int y = y0 + wv * GL_ROWS + i;
-            if (y >= a.H) break;
-            const int pa = (halo + wv * GL_ROWS + i) * lpitch + halo + lane;
-            const uint8_t* pb = reinterpret_cast<const uint8_t*>(gl_tile) + 4 * pa;
-            const uint32_t c = gl_tile[pa] & 0xFFFFu;
-            const uint32_t init = a.margin - (c << 16);
-            uint32_t signs = 0, near = 0;  // sample p at bit P-1-p
-            auto sample = [&](int p) {
-                // t = (sample - centre) + margin in 1/65536 gray levels
-                const uint32_t top = *reinterpret_cast<const uint32_t*>(pb + a.otop[p]);
-                const uint32_t bot = *reinterpret_cast<const uint32_t*>(pb + a.obot[p]);
-                const uint32_t t = dot2(top, a.wtop[p], dot2(bot, a.wbot[p], init));
-                signs = __builtin_amdgcn_alignbit(signs, t, 31);
-                // 0 <= t <= 2*margin: too close to call (t < lim as unsigned; lim = 0 never flags).  Written as an
-                // add so that the comparison's carry feeds the doubling of near directly.
-                near = near + near + (t < a.lim[p] ? 1u : 0u);
+    // 0/1 changes between consecutive samples (not circular), as scikit-image counts them; the reversed bit order
+    // of the sign words changes neither that count nor the number of ones
+    const uint32_t pairmask = (P >= 2) ? ((1u << (P - 1)) - 1u) : 0u;
+    auto count_pixel = [&](uint32_t bits, int y, int xx) {
+        const int changes = __popc((bits ^ (bits >> 1)) & pairmask);
+        const int code = (changes <= 2) ? __popc(bits) : P + 1;
+        atomicAdd(&hist[(lane & (GL_COPIES - 1)) * GL_HSTRIDE + code], 1u);
+        if (a.codes) a.codes[((int64_t)frame * a.H + y) * a.W + xx] = (uint8_t)code;
+    };
+    // the undecided samples (bits of near) of pixel (y, xx) in skimage's bilinear_interpolation, operation by operation
+    auto settle = [&](uint32_t bits, uint32_t near, int y, int xx) -> uint32_t {
+        const double c = (double)(gl_tile[(y - y0 + halo) * lpitch + (xx - x0 + halo)] & 0xFFFFu);
+        while (near != 0) {
+            const int b = __ffs(near) - 1;
+            near &= near - 1;
+            const int p = P - 1 - b;
+            const double rf = (double)y + offs[0][p], cf = (double)xx + offs[1][p];
+            const double fr = floor(rf), fc = floor(cf);
+            const int minr = (int)fr, minc = (int)fc;
+            const int maxr = (int)ceil(rf), maxc = (int)ceil(cf);
+            const double dr = rf - fr, dc = cf - fc;
+            auto px = [&](int yy, int xq) -> double {
+                return (double)(gl_tile[(yy - y0 + halo) * lpitch + (xq - x0 + halo)] & 0xFFFFu);
             };
-            if (PT > 0) {
-#pragma unroll
-                for (int p = 0; p < PT; ++p) sample(p);
+            const double tl = px(minr, minc), tr = px(minr, maxc), bl = px(maxr, minc), br = px(maxr, maxc);
+            const double top = (1.0 - dc) * tl + dc * tr;
+            const double bottom = (1.0 - dc) * bl + dc * br;
+            const double t = (1.0 - dr) * top + dr * bottom;
+            const uint32_t bit = (t - c >= 0.0) ? 1u : 0u;
+            bits = (bits & ~(1u << b)) | (bit << b);
+        }
+        return bits;
+    };
+    uint32_t qn = 0;  // entries in this wave's queue (wave-uniform)
+    for (int i = 0; i < GL_ROWS; ++i) {
+        const int y = y0 + wv * GL_ROWS + i;
+        if (y >= a.H) break;
+        const int pa = (halo + wv * GL_ROWS + i) * lpitch + halo + lane;
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(gl_tile) + 4 * pa;
+        const uint8_t* pr = pb - 4 * (halo * lpitch + halo);  // RING: every cell offset is non-negative from here
+        const uint32_t c = gl_tile[pa] & 0xFFFFu;
+        const uint32_t init = a.margin - (c << 16);
+        uint32_t signs = 0, near = 0;  // sample p at bit P-1-p
+        auto sample = [&](int p) {
+            // t = (sample - centre) + margin in 1/65536 gray levels
+            uint32_t top, bot;
+            if constexpr (RING) {
+                top = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::top(p));
+                bot = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::bot(p));
             } else {
-                for (int p = 0; p < P; ++p) sample(p);
+                top = *reinterpret_cast<const uint32_t*>(pb + a.otop[p]);
+                bot = *reinterpret_cast<const uint32_t*>(pb + a.obot[p]);
             }
-            uint32_t bits = ~signs & pmask;  // LBP bit = sample >= centre
-            while (near != 0) {
-                const int b = __ffs(near) - 1;
-                near &= near - 1;
-                const int p = P - 1 - b;
-                // skimage's bilinear_interpolation, operation by operation
-                const double rf = (double)y + offs[0][p], cf = (double)x + offs[1][p];
-                const double fr = floor(rf), fc = floor(cf);
-                const int minr = (int)fr, minc = (int)fc;
-                const int maxr = (int)ceil(rf), maxc = (int)ceil(cf);
-                const double dr = rf - fr, dc = cf - fc;
-                auto px = [&](int yy, int xx) -> double {
-                    return (double)(gl_tile[(yy - y0 + halo) * lpitch + (xx - x0 + halo)] & 0xFFFFu);
-                };
-                const double tl = px(minr, minc), tr = px(minr, maxc), bl = px(maxr, minc), br = px(maxr, maxc);
-                const double top = (1.0 - dc) * tl + dc * tr;
-                const double bottom = (1.0 - dc) * bl + dc * br;
-                const double t = (1.0 - dr) * top + dr * bottom;
-                const uint32_t bit = (t - (double)c >= 0.0) ? 1u : 0u;
-                bits = (bits & ~(1u << b)) | (bit << b);
+            const uint32_t t = dot2(top, a.wtop[p], dot2(bot, a.wbot[p], init));
+            signs = __builtin_amdgcn_alignbit(signs, t, 31);
+            // 0 <= t <= 2*margin: too close to call (t < lim as unsigned; lim = 0 never flags).  Written as an
+            // add so that the comparison's carry feeds the doubling of near directly.
+            near = near + near + (t < a.lim[p] ? 1u : 0u);
+        };
+        if constexpr (PT > 0) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) sample(p);
+        } else {
+            for (int p = 0; p < P; ++p) sample(p);
+        }
+        const uint32_t bits = ~signs & pmask;  // LBP bit = sample >= centre
+        const bool valid = x < a.W;
+        const bool und = valid && near != 0;
+        if (valid && !und) count_pixel(bits, y, x);
+        // Undecided pixels (ties, mostly) wait in the wave's queue for the end of the strip, where any lane takes
+        // any entry: the fp64 replay then costs ceil(queued / 64) rounds instead of the worst lane's count per row.
+        const unsigned long long um = __ballot(und);
+        if (um != 0) {
+            const uint32_t cnt = (uint32_t)__popcll(um);
+            if (qn + cnt <= GL_QUEUE) {
+                if (und) {
+                    const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u));
+                    queue[wv][pos] = make_uint2(bits | ((uint32_t)i << 24), near | ((uint32_t)lane << 24));
+                }
+                qn += cnt;
+            } else if (und) {
+                count_pixel(settle(bits, near, y, x), y, x);  // a full queue: flat content, every lane is busy anyway
             }
-            // 0/1 changes between consecutive samples (not circular), as scikit-image counts them; the
-            // reversed bit order changes neither that count nor the number of ones
-            const uint32_t pairmask = (P >= 2) ? ((1u << (P - 1)) - 1u) : 0u;
-            const int changes = __popc((bits ^ (bits >> 1)) & pairmask);
-            const int code = (changes <= 2) ? __popc(bits) : P + 1;
-            atomicAdd(&hist[(lane & (GL_COPIES - 1)) * GL_HSTRIDE + code], 1u);
-            if (a.codes) a.codes[((int64_t)frame * a.H + y) * a.W + x] = (uint8_t)code;
+        }
+    }
+    for (uint32_t qb = 0; qb < qn; qb += 64) {
+        if (qb + lane < qn) {
+            const uint2 e = queue[wv][qb + lane];
+            const int y = y0 + wv * GL_ROWS + (int)(e.x >> 24), xx = x0 + (int)(e.y >> 24);
+            count_pixel(settle(e.x & 0xFFFFFFu, e.y & 0xFFFFFFu, y, xx), y, xx);
         }
     }
     __syncthreads();
@@ -195,7 +259,7 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
     // odd pitch in 32-bit entries: consecutive tile rows start in different LDS banks
     const int lpitch = (GL_TILE + 2 * halo) | 1;
     const size_t lds = (size_t)(GL_TILE + 2 * halo) * lpitch * sizeof(uint32_t);
-    if (lds > 60 * 1024) return false;  // radius beyond what one tile with its halo can hold
+    if (lds > 52 * 1024) return false;  // radius beyond what one tile with its halo can hold (static LDS takes 11 of the 64 KB)
     a.halo = halo; a.lpitch = lpitch;
     for (int p = 0; p < 24; ++p) { a.otop[p] = 0; a.obot[p] = 0; a.wtop[p] = 0; a.wbot[p] = 0; a.lim[p] = 0; }
     for (int p = 0; p < P; ++p) {
@@ -232,12 +296,26 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
     a.margin = (uint32_t)ceil(worst) + 2u;
     for (int p = 0; p < P; ++p) a.lim[p] = (dr1[p] == 0 && dc1[p] == 0) ? 0u : 2u * a.margin + 1u;
     dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
-    switch (P) {
-        case 8: hipLaunchKernelGGL(lbp_generic_kernel<8>, grid, dim3(256), lds, s, a); break;
-        case 16: hipLaunchKernelGGL(lbp_generic_kernel<16>, grid, dim3(256), lds, s, a); break;
-        case 24: hipLaunchKernelGGL(lbp_generic_kernel<24>, grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(lbp_generic_kernel<0>, grid, dim3(256), lds, s, a); break;
-    }
+    // the compile-time cell tables apply when this launch's geometry is theirs (it is for R = 2 at P = 16 and R = 3 at
+    // P = 24, whatever rounding of the offsets the caller's platform produced is checked here, not assumed)
+    auto ring_ok = [&](auto ring) {
+        typedef decltype(ring) G;
+        if (halo != G::HALO || lpitch != G::LPITCH) return false;
+        for (int p = 0; p < P; ++p)
+            if (fr[p] != G::fr(p) || fc[p] != G::fc(p) || dr1[p] != G::d1(p) || dc1[p] != G::d1(p)) return false;
+        return true;
+    };
+    if (P == 16 && ring_ok(Ring<16>()))
+        hipLaunchKernelGGL((lbp_generic_kernel<16, true>), grid, dim3(256), lds, s, a);
+    else if (P == 24 && ring_ok(Ring<24>()))
+        hipLaunchKernelGGL((lbp_generic_kernel<24, true>), grid, dim3(256), lds, s, a);
+    else
+        switch (P) {
+            case 8: hipLaunchKernelGGL((lbp_generic_kernel<8, false>), grid, dim3(256), lds, s, a); break;
+            case 16: hipLaunchKernelGGL((lbp_generic_kernel<16, false>), grid, dim3(256), lds, s, a); break;
+            case 24: hipLaunchKernelGGL((lbp_generic_kernel<24, false>), grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL((lbp_generic_kernel<0, false>), grid, dim3(256), lds, s, a); break;
+        }
     hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, lbp_generic_tiles(g), P + 2, acc, hist_slot);
     return true;
 }
