@@ -156,6 +156,12 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
             uint32_t top, bot;
             if constexpr (RING) {
                 top = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::top(p));
+                if (Ring<PT>::d1(p) == 0) {
+                    // the sample is a pixel: one read, one shift-and-add, never undecided
+                    signs = __builtin_amdgcn_alignbit(signs, (top << 16) + init, 31);
+                    near = near + near;
+                    return;
+                }
                 bot = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::bot(p));
             } else {
                 top = *reinterpret_cast<const uint32_t*>(pb + a.otop[p]);
