@@ -89,6 +89,48 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     const int trows = GL_TILE + 2 * halo;
 
     const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
+    // Tiles that lie inside the image with their halo (and one more column for the last pair) need no zero fill:
+    // a thread takes eight entries of a row from twelve bytes (three unaligned 32-bit loads), every load of the
+    // tile is issued before the first LDS store, and there is no division.  (The general loop below waits for
+    // two dependent byte loads per entry, nineteen times in a row per thread.)
+    const bool inside = x0 - halo >= 0 && y0 - halo >= 0 && x0 + GL_TILE + halo + 1 <= a.W && y0 + GL_TILE + halo <= a.H;
+    if (inside) {
+        constexpr int SEG = 8;
+        const int segs = (GL_TILE + 2 * halo + SEG - 1) / SEG;  // per row; the last one may run past the row's entries
+        const int tasks = trows * segs;
+        constexpr int ROUNDS = 4;  // tasks in flight per thread: 1024 per pass of the outer loop (a halo of 3 has 630)
+        uint32_t w[ROUNDS][3];
+        int rr[ROUNDS], ss[ROUNDS];
+        for (int t0 = 0; t0 < tasks; t0 += 256 * ROUNDS) {
+#pragma unroll
+            for (int k = 0; k < ROUNDS; ++k) {
+                const int t = t0 + tid + 256 * k;
+                rr[k] = t / segs;
+                ss[k] = t - rr[k] * segs;
+                if (t < tasks) {
+                    const uint8_t* src = gp + (int64_t)(y0 - halo + rr[k] + GRAY_YOFF) * a.gpitch + GRAY_XOFF + x0 - halo + SEG * ss[k];
+                    __builtin_memcpy(&w[k][0], src, 4);
+                    __builtin_memcpy(&w[k][1], src + 4, 4);
+                    __builtin_memcpy(&w[k][2], src + 8, 4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ROUNDS; ++k) {
+                const int t = t0 + tid + 256 * k;
+                if (t < tasks) {
+                    uint32_t* dst = gl_tile + rr[k] * lpitch + SEG * ss[k];
+                    const int left = lpitch - SEG * ss[k];  // entries of the row from here on
+#pragma unroll
+                    for (int j = 0; j < SEG; ++j) {
+                        // bytes j and j+1 of the twelve, one per 16-bit half
+                        const uint32_t lo = w[k][j >> 2], hi = w[k][(j + 1) >> 2];
+                        const uint32_t e = ((lo >> (8 * (j & 3))) & 0xFFu) | (((hi >> (8 * ((j + 1) & 3))) & 0xFFu) << 16);
+                        if (j < left) dst[j] = e;
+                    }
+                }
+            }
+        }
+    } else
     for (int i = tid; i < trows * lpitch; i += 256) {
         const int r = i / lpitch, cidx = i - r * lpitch;
         const int gy = y0 - halo + r, gx = x0 - halo + cidx;
