@@ -104,9 +104,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-fed", action="store_true",
                     help="also report the PCIe-inclusive rate from a pinned host batch (never the headline value)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="two clips in flight through stx_submit_batch_device / stx_wait instead of one blocking "
-                         "call per step")
+    ap.add_argument("--blocking", action="store_true",
+                    help="one blocking call per step instead of two clips in flight through stx_submit_batch_device / "
+                         "stx_wait (the default: the host queues clip i+1 and collects clip i-1 while the GPU works on "
+                         "clip i, so the device does not idle between calls)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = the library's choice)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the CPU baseline legs")
     args = ap.parse_args()
@@ -192,9 +193,9 @@ def main() -> None:
             keep_rows(out, keep)
 
     def run_steps(n: int, keep: bool) -> None:
-        """n steps; with --pipeline, software-pipelined two deep through the asynchronous entry point: while
+        """n steps; unless --blocking, software-pipelined two deep through the asynchronous entry point: while
         the GPU works on clip i the host collects clip i-1 and queues clip i+1."""
-        if not args.pipeline or cfg["extended"] or nf > ctx.max_async_frames(h, w):
+        if args.blocking or cfg["extended"] or nf > ctx.max_async_frames(h, w):
             for i in range(n):
                 step(i, keep=i if keep else -1)
             return
@@ -300,7 +301,7 @@ def main() -> None:
                                    + f" (BASELINE {cfg['row']})",
                        "frames_per_step_per_gpu": nf, "height": h, "width": w, "sharding": "by clip, one rank per GPU",
                        "distinct_clips_per_gpu": n_clips, "video_id": "step * world + rank",
-                       "submission": "blocking" if not args.pipeline else "two clips in flight (stx_submit_batch_device / stx_wait)",
+                       "submission": "blocking" if args.blocking else "two clips in flight (stx_submit_batch_device / stx_wait)",
                        "untimed_steps_before_warmup": PREWARM_STEPS},
             "roofline": {
                 "bound": "hbm", "kernel": dom + " (" + groups[dom]["kernels"] + ")",
