@@ -192,10 +192,13 @@ def main() -> None:
         if keep >= 0:
             keep_rows(out, keep)
 
+    # the extended entry point has no asynchronous form, and a clip must fit one asynchronous submission
+    pipelined = not (args.blocking or cfg["extended"] or nf > ctx.max_async_frames(h, w))
+
     def run_steps(n: int, keep: bool) -> None:
         """n steps; unless --blocking, software-pipelined two deep through the asynchronous entry point: while
         the GPU works on clip i the host collects clip i-1 and queues clip i+1."""
-        if args.blocking or cfg["extended"] or nf > ctx.max_async_frames(h, w):
+        if not pipelined:
             for i in range(n):
                 step(i, keep=i if keep else -1)
             return
@@ -301,7 +304,7 @@ def main() -> None:
                                    + f" (BASELINE {cfg['row']})",
                        "frames_per_step_per_gpu": nf, "height": h, "width": w, "sharding": "by clip, one rank per GPU",
                        "distinct_clips_per_gpu": n_clips, "video_id": "step * world + rank",
-                       "submission": "blocking" if args.blocking else "two clips in flight (stx_submit_batch_device / stx_wait)",
+                       "submission": "blocking" if not pipelined else "two clips in flight (stx_submit_batch_device / stx_wait)",
                        "untimed_steps_before_warmup": PREWARM_STEPS},
             "roofline": {
                 "bound": "hbm", "kernel": dom + " (" + groups[dom]["kernels"] + ")",
