@@ -311,15 +311,20 @@ void finalize(const FrameAcc& a, const Geom& g, int P, stx_metrics* m) {
 // its value (the parity budget is 1e-4).  Bins well above the noise are perturbed by a relative, zero-mean amount
 // that cancels in the sums; a bin near zero is not: its ln(|F|+1) rises by up to err/(|F|+1).  With l = ln(|F|+1)
 // and mean mu, the variance then changes by at most 2 err sum_small |mu - l| / (|F|+1) / N to first order, which
-// the column pass's t1 = sum 1/(|F|+1) and t2 = sum l/(|F|+1) over the small bins give.
+// the column pass's t1 = sum 1/(|F|+1) and t2 = sum l/(|F|+1) over the small bins give.  err scales with the
+// root-mean-square of the transform's input (gray minus the frame's first gray level), which Parseval reads off the
+// spectrum: sum |F|^2 = fh fw sum (gray - m)^2.  The small bins were picked at launch for the largest possible
+// input; counting more bins than a quiet frame's noise reaches only makes the bound more careful.  A constant frame
+// has no energy and no noise: its spectrum is exactly zero, as in the reference.
 bool fft_needs_f64(const FrameAcc& a, const Geom& g) {
     if (!(a.fft_t1 > 0.0)) return false;
     const double nf = (double)g.fh * (double)g.fw;
+    const double rms = sqrt((a.fft_e2 > 0.0 ? a.fft_e2 : 0.0) / (nf * nf));
     const double mu = a.fft_sum / nf;
     const double var = a.fft_sumsq / nf - mu * mu;
     const double lmax = log((double)fft_small_threshold(g.fh, g.fw) + 1.0);
     const double dev = mu >= lmax ? mu * a.fft_t1 - a.fft_t2 : lmax * a.fft_t1;
-    const double dvar = 2.0 * fft_f32_bin_error(g.fh, g.fw) * dev / nf;
+    const double dvar = 2.0 * fft_f32_bin_error_rms(g.fh, g.fw, rms < 255.0 ? rms : 255.0) * dev / nf;
     return dvar > 4e-5 * (var > 0.0 ? var : 0.0);  // d(std)/std = dvar / (2 var)
 }
 

@@ -83,7 +83,7 @@ struct FftColsArgs {
 
 __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     extern __shared__ float2 lds[];
-    __shared__ double red[4][4];
+    __shared__ double red[5][4];
     const int n = a.fh, cb = a.cb, tid = threadIdx.x;
     cf* buf0 = reinterpret_cast<cf*>(lds);
     cf* buf1 = buf0 + cb * n;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
     const cf* f = buf0;
     if (a.plan.bz_m) fft_bluestein<float>(buf0, n, a.plan.bz_m, reinterpret_cast<const cf*>(a.tw), tid, 256);
     else f = fft_run<float>(buf0, buf1, a.plan, cb, reinterpret_cast<const cf*>(a.tw), tid, 256);
-    double s = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+    double s = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0, e2 = 0.0;
     const float dc_fix = (float)a.gray0[(int64_t)frame * a.gstride] * (float)a.fh * (float)a.fw;
     for (int c = 0; c < cb; ++c) {
         const int k = k0 + c;
@@ -109,9 +109,10 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
         const double wgt = (k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0;
         // accumulate in fp64: the variance is a difference of two nearly equal sums
         double ls = 0.0, ls2 = 0.0;
-        float lt1 = 0.f, lt2 = 0.f;
+        float lt1 = 0.f, lt2 = 0.f, le2 = 0.f;
         for (int y = tid; y < n; y += 256) {
             cf v = f[c * n + y];
+            le2 += v.x * v.x + v.y * v.y;
             if (k == 0 && y == 0) v.x += dc_fix;
             const float mag = sqrtf(v.x * v.x + v.y * v.y);
             const float lf = logf(mag + 1.0f);
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
         s2 += wgt * ls2;
         t1 += wgt * (double)lt1;
         t2 += wgt * (double)lt2;
+        e2 += wgt * (double)le2;
     }
     // deterministic block reduction: fixed shuffle tree, then waves in order
 #pragma unroll
@@ -136,12 +138,13 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(FftColsArgs a) {
         s2 += __shfl_xor(s2, o, 64);
         t1 += __shfl_xor(t1, o, 64);
         t2 += __shfl_xor(t2, o, 64);
+        e2 += __shfl_xor(e2, o, 64);
     }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = s2; red[2][tid >> 6] = t1; red[3][tid >> 6] = t2; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = s2; red[2][tid >> 6] = t1; red[3][tid >> 6] = t2; red[4][tid >> 6] = e2; }
     __syncthreads();
     if (tid == 0) {
         auto tot = [&](int q) { return ((red[q][0] + red[q][1]) + red[q][2]) + red[q][3]; };
-        a.part[(int64_t)frame * a.nblocks + blockIdx.x] = FftPart{tot(0), tot(1), tot(2), tot(3)};
+        a.part[(int64_t)frame * a.nblocks + blockIdx.x] = FftPart{tot(0), tot(1), tot(2), tot(3), tot(4)};
     }
 }
 
@@ -314,10 +317,11 @@ hipError_t fft_set_lds_limits() {
 // whose root-mean-square over the bins is sqrt(sum x^2) <= 255 sqrt(N) (Parseval); 3e-7 leaves room for the
 // log2(N)/2 stages' accumulation and the twiddle errors.
 // A chirp-z dimension goes through two transforms four times its length and three products: four times the noise.
-double fft_f32_bin_error(int fh, int fw) {
+double fft_f32_bin_error_rms(int fh, int fw, double rms) {
     FftPlan ph, pw;
     const bool bz = (make_fft_plan(fh, &ph) && ph.bz_m) || (make_fft_plan(fw, &pw) && pw.bz_m);
-    return (bz ? 4.0 : 1.0) * 3e-7 * 255.0 * sqrt((double)fh * (double)fw);
+    return (bz ? 4.0 : 1.0) * 3e-7 * rms * sqrt((double)fh * (double)fw);
 }
+double fft_f32_bin_error(int fh, int fw) { return fft_f32_bin_error_rms(fh, fw, 255.0); }
 
 }  // namespace stx

@@ -806,14 +806,19 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     // the last pass hands its outputs straight to the log-magnitude reduction
     struct LogMagSink {
         double ls = 0.0, ls2 = 0.0;
-        float t1 = 0.f, t2 = 0.f;
+        float t1 = 0.f, t2 = 0.f, e2 = 0.f;
         float dc_fix, small;
         bool dc_col;
         __device__ __forceinline__ void operator()(int y, float2 v) {
-            if (dc_col && y == 0) v.x += dc_fix;
+            float p = v.x * v.x + v.y * v.y;
+            e2 += p;  // the energy of gray - m: what the transform's rounding noise scales with
+            if (dc_col && y == 0) {
+                v.x += dc_fix;
+                p = v.x * v.x + v.y * v.y;
+            }
             // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
             // the statistic; the sums stay in fp64 because the variance is a small difference
-            const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+            const float mag = __builtin_amdgcn_sqrtf(p);
             const float lf = __builtin_amdgcn_logf(mag + 1.0f) * 0.69314718055994530942f;
             const double l = (double)lf;
             ls += l;
@@ -835,19 +840,20 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
         transform_to<P>(buf, a.tw, t, sink);
     }
     double ls = sink.ls, ls2 = sink.ls2;
-    float t1 = sink.t1, t2 = sink.t2;
-    if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; t1 = 0.f; t2 = 0.f; }  // columns past the half spectrum hold no data
+    float t1 = sink.t1, t2 = sink.t2, e2 = sink.e2;
+    if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; t1 = 0.f; t2 = 0.f; e2 = 0.f; }  // columns past the half spectrum hold no data
 #pragma unroll
     for (int o = LPT / 2; o > 0; o >>= 1) {
         ls += __shfl_xor(ls, o, 64);
         ls2 += __shfl_xor(ls2, o, 64);
         t1 += __shfl_xor(t1, o, 64);
         t2 += __shfl_xor(t2, o, 64);
+        e2 += __shfl_xor(e2, o, 64);
     }
     if (t == 0) {
         // columns 0 and (even W) W/2 are their own mirror images; every other column stands for two
         const double wgt = (k >= a.fwh) ? 0.0 : ((k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0);
-        a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = FftPart{wgt * ls, wgt * ls2, wgt * (double)t1, wgt * (double)t2};
+        a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = FftPart{wgt * ls, wgt * ls2, wgt * (double)t1, wgt * (double)t2, wgt * (double)e2};
     }
 }
 

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
                                                            int htiles, const FftPart* __restrict__ fpart, int nfparts,
                                                            FrameAcc* __restrict__ acc) {
     __shared__ unsigned long long red[16][17];
-    __shared__ double dred[4][4];
+    __shared__ double dred[5][4];
     __shared__ uint32_t ered[4];
     const int frame = blockIdx.x, tid = threadIdx.x;
     // 16 quantities x 16 tile lanes
@@ -292,13 +292,14 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
     }
     uint32_t e = 0;
     for (int i = tid; i < htiles; i += 256) e += tile_count[(int64_t)frame * htiles + i];
-    double fs = 0.0, fs2 = 0.0, ft1 = 0.0, ft2 = 0.0;
+    double fs = 0.0, fs2 = 0.0, ft1 = 0.0, ft2 = 0.0, fe2 = 0.0;
     for (int i = tid; i < nfparts; i += 256) {
         const FftPart p = fpart[(int64_t)frame * nfparts + i];
         fs += p.s;
         fs2 += p.s2;
         ft1 += p.t1;
         ft2 += p.t2;
+        fe2 += p.e2;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -307,10 +308,11 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
         fs2 += __shfl_xor(fs2, o, 64);
         ft1 += __shfl_xor(ft1, o, 64);
         ft2 += __shfl_xor(ft2, o, 64);
+        fe2 += __shfl_xor(fe2, o, 64);
     }
     if ((tid & 63) == 0) {
         ered[tid >> 6] = e;
-        dred[0][tid >> 6] = fs; dred[1][tid >> 6] = fs2; dred[2][tid >> 6] = ft1; dred[3][tid >> 6] = ft2;
+        dred[0][tid >> 6] = fs; dred[1][tid >> 6] = fs2; dred[2][tid >> 6] = ft1; dred[3][tid >> 6] = ft2; dred[4][tid >> 6] = fe2;
     }
     __syncthreads();
     FrameAcc* fa = acc + frame;
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256) void frame_reduce_kernel(const uint32_t* __res
         fa->fft_sumsq = ((dred[1][0] + dred[1][1]) + dred[1][2]) + dred[1][3];
         fa->fft_t1 = ((dred[2][0] + dred[2][1]) + dred[2][2]) + dred[2][3];
         fa->fft_t2 = ((dred[3][0] + dred[3][1]) + dred[3][2]) + dred[3][3];
+        fa->fft_e2 = ((dred[4][0] + dred[4][1]) + dred[4][2]) + dred[4][3];
     }
 }
 

@@ -22,6 +22,7 @@ struct FrameAcc {
     double fft_sum;
     double fft_sumsq;
     double fft_t1, fft_t2;  // sums over the near-zero bins of the spectrum (FftPart)
+    double fft_e2;          // sum of |F|^2 over the spectrum of gray - m (the transform's input energy times fh*fw)
     // frame-quality sums (only filled when stx_params.quality_stats is set)
     long long lap_sum;
     unsigned long long lap_sumsq;
@@ -85,6 +86,7 @@ void fft_fill_table(const FftPlan& p, double* out);
 struct FftPart {
     double s, s2;   // sum l, sum l^2
     double t1, t2;  // sum 1/(|F|+1), sum l/(|F|+1) over the small bins
+    double e2;      // sum |F|^2, before the gray level m goes back into bin (0,0)
 };
 
 // ---- launchers (each file owns its kernels) ----
@@ -137,6 +139,8 @@ void launch_fft_cols(hipStream_t s, const uint8_t* gray, const float2* spec, int
 // Bound on the absolute error of one bin of the fp32 transform of an fh x fw region of 8-bit pixels, and the
 // magnitude below which a bin counts as small.
 double fft_f32_bin_error(int fh, int fw);
+// The same bound for a signal of known energy: rms = sqrt(sum (gray - m)^2 / (fh*fw)) in place of 255.
+double fft_f32_bin_error_rms(int fh, int fw, double rms);
 inline float fft_small_threshold(int fh, int fw) { return (float)(64.0 * fft_f32_bin_error(fh, fw)); }
 
 // The same transform and statistic in double precision for single frames (stx_fft64.hip): used for the frames whose

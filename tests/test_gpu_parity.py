@@ -296,6 +296,12 @@ def test_structured_frames_are_transformed_in_fp64(ctx, coracle):
         r = ctx.analyze_frames([f])[0]
         assert not (r.flags & FLAG_FFT_F64), kind
         assert r.frequency_anomaly == pytest.approx(_np_freq(coracle.gray(f)), rel=REL)
+    # quiet frames: the noise of the fp32 transform scales with the input's energy, so a constant frame (no energy:
+    # an exactly zero spectrum) and a two-level frame stay on the fp32 path and agree all the same
+    for f in (np.full((h, w, 3), 93, np.uint8), synth_frame("tie", SEED, 50, 0, h, w), synth_frame("flat", SEED, 50, 0, h, w)):
+        r = ctx.analyze_frames([f])[0]
+        assert not (r.flags & FLAG_FFT_F64)
+        assert r.frequency_anomaly == pytest.approx(_np_freq(coracle.gray(f)), rel=REL, abs=1e-9)
     # the knob: every frame in fp64 agrees with numpy to rounding; fp32 only never sets the flag
     f = synth_frame("natural", SEED, 50, 1, h, w)
     p = ctx.default_params(); p.fft_exact = 1
