@@ -75,6 +75,31 @@ def test_1080p_structured_frequency_statistic(ctx, coracle, kind):
         assert ctx.analyze_frames([wide], p)[0].frequency_anomaly == pytest.approx(want, rel=1e-9)
 
 
+def test_mixed_clip_at_full_size(ctx, coracle):
+    """Several frames deep at the big shapes: every content class in one 1080p batch (one frame of each goes to the
+    oracle), and three 4K frames of different classes through the default call (whole-frame FFT)."""
+    h, w = 1080, 1920
+    kinds = ("natural", "noise", "ramp", "flat", "tie", "step")
+    frames = [synth_frame(k, SEED + 6, 3, i, h, w) for i, k in enumerate(kinds) for _ in range(2)]
+    recs = ctx.analyze_frames(frames)
+    assert len(recs) == len(frames)
+    for i in range(0, len(frames), 2):
+        m = coracle.analyze_frame(frames[i])
+        assert _ints(recs[i]) == _ints(m), kinds[i // 2]
+        for a, b, k in zip(_floats(recs[i]), _floats(m), O.METRIC_KEYS + ("texture_score",)):
+            assert a == pytest.approx(b, rel=1e-4, abs=1e-9), (kinds[i // 2], k)
+        # the same frame again in the batch: same record, whatever its neighbours are
+        assert _ints(recs[i + 1]) == _ints(recs[i]) and _floats(recs[i + 1]) == _floats(recs[i])
+    h, w = 2160, 3840
+    frames = [synth_frame(k, SEED + 7, 4, i, h, w) for i, k in enumerate(("step", "natural", "tie"))]
+    recs = ctx.analyze_frames(frames)
+    for f, r, k in zip(frames, recs, ("step", "natural", "tie")):
+        m = coracle.analyze_frame(f)
+        assert _ints(r) == _ints(m), k
+        for a, b, key in zip(_floats(r), _floats(m), O.METRIC_KEYS + ("texture_score",)):
+            assert a == pytest.approx(b, rel=1e-4, abs=1e-9), (k, key)
+
+
 @pytest.mark.parametrize("h,w,cell", PATCHWORK_CASES)
 def test_flat_patches_vs_skimage_golden(ctx, h, w, cell):
     """Flat patches: every interior pixel is an exact tie of the four diagonal samples, resolved from the
