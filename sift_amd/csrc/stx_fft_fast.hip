@@ -872,11 +872,11 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     X(512, 8, 8, 8, 1, 64)     \
     X(540, 9, 10, 6, 1, 64)    \
     X(640, 5, 16, 8, 1, 64)    \
-    X(720, 9, 10, 8, 1, 64)    \
+    X(720, 9, 16, 5, 1, 64)    \
     X(768, 3, 16, 16, 1, 64)   \
     X(960, 15, 8, 8, 1, 64)    \
     X(1024, 16, 8, 8, 1, 64)   \
-    X(1080, 9, 12, 10, 1, 64)  \
+    X(1080, 9, 20, 6, 1, 64)   \
     X(1280, 5, 16, 16, 1, 64)  \
     X(1440, 9, 16, 10, 1, 64)  \
     X(1920, 15, 16, 8, 1, 64)  \
