@@ -102,6 +102,12 @@ __device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc
     asm("v_sad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
     return d;
 }
+// a.lo + a.hi + acc (the sum of absolute differences against an inline zero: no register holds the zero)
+__device__ __forceinline__ uint32_t sum_u16(uint32_t a, uint32_t acc) {
+    uint32_t d;
+    asm("v_sad_u16 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(acc));
+    return d;
+}
 __device__ __forceinline__ uint32_t dot2(uint32_t a, uint32_t b, uint32_t acc) {
     return __builtin_amdgcn_udot2(asU(a), asU(b), acc, false);
 }
@@ -381,9 +387,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 {
                     const uint32_t sum3 = rw[1].rs + rw[2].rs + rw[3].rs;  // at most 2295 per half
                     const uint32_t v = pk_min(pk_sub_sat(pk_mul<9>(c2), sum3), 0x00FF00FFu);
-                    hp_s = sad_u16(v, 0, hp_s);
+                    hp_s = sum_u16(v, hp_s);
                     hp_q = dot2(v, v, hp_q);
-                    gr_s = sad_u16(c2, 0, gr_s);
+                    gr_s = sum_u16(c2, gr_s);
                 }
                 // ---- Gaussian residual
                 {
@@ -439,7 +445,6 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 {
                     const uint32_t m = mg[1].M;
                     const uint32_t nz = pk_sub(a.low2, m);  // negative where m > low
-                    uint32_t ks = 0, kc = 0;
                     if (__any((nz & 0x80008000u) != 0)) {
                         const uint32_t ax = mg[1].ax, ay = mg[1].ay;
                         const uint32_t q22 = pk_shr<7>(pk_mad<53>(ax, pk_shr<8>(pk_mul<5>(ax))));
@@ -455,11 +460,14 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         // the second neighbour is compared with >= for horizontal / vertical gradients:
                         // m >= nb is m > nb - 1
                         nb = pk_add(nb, bfi(nothoriz, vert, 0xFFFFFFFFu));
-                        kc = pk_sub(na, m) & pk_sub(nb, m) & nz;
-                        ks = kc & pk_sub(a.high2, m);
+                        const uint32_t kc = pk_sub(na, m) & pk_sub(nb, m) & nz;
+                        const uint32_t ks = kc & pk_sub(a.high2, m);
+                        accC = pk_mad<2>(accC, pk_shr<15>(kc));
+                        accS = pk_mad<2>(accS, pk_shr<15>(ks));
+                    } else {  // no candidate in the row: the words just move on (a half holds at most 15 bits here)
+                        accC += accC;
+                        accS += accS;
                     }
-                    accC = pk_mad<2>(accC, pk_shr<15>(kc));
-                    accS = pk_mad<2>(accS, pk_shr<15>(ks));
                 }
                 // ---- slide down one row
 #pragma unroll
