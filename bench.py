@@ -108,6 +108,9 @@ def main() -> None:
                     help="one blocking call per step instead of two clips in flight through stx_submit_batch_device / "
                          "stx_wait (the default: the host queues clip i+1 and collects clip i-1 while the GPU works on "
                          "clip i, so the device does not idle between calls)")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="bracket every kernel with HIP events in the timed region, not only the dominant group's "
+                         "(costs a few percent of throughput: each event pair delays its stream's next kernel)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = the library's choice)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the CPU baseline legs")
     args = ap.parse_args()
@@ -222,9 +225,24 @@ def main() -> None:
 
     # untimed: the first calls size the workspace and the GPU leaves its idle clocks; then the W warm-up steps
     run_steps(PREWARM_STEPS if nf * h * w <= 150 * 1080 * 1920 else 3, keep=False)
-    run_steps(args.warmup, keep=False)
+    # one clip with every kernel back to back on one stream and an event pair around each: per-kernel durations with
+    # the device to itself.  The group of kernels that takes longest here is the dominant one, and the only one
+    # bracketed by events in the timed region: an event pair costs the stream a few microseconds on either side of
+    # the kernel, which adds up over a chain of dependent kernels.
+    ctx.set_concurrency(False)
     ctx.get_timing(reset=True)
     ctx.set_timing(True)
+    step(0)
+    torch.cuda.synchronize()
+    ctx.set_timing(False)
+    solo = ctx.get_timing(reset=True)
+    ctx.set_concurrency(True)
+    solo_chunks = max(solo["kernels"]["stencil"]["launches"], 1)  # the stencil kernel runs once per chunk of frames
+    solo_ms = {g: sum(solo["kernels"][k]["ms"] for k in ks) / solo_chunks for g, ks in GROUPS.items()}
+    dom = max(GROUPS, key=lambda g: solo_ms[g])
+    run_steps(args.warmup, keep=False)
+    ctx.get_timing(reset=True)
+    ctx.set_timing(True, kinds=None if args.time_all_kernels else GROUPS[dom])
     sync()
     t0 = time.perf_counter()
     run_steps(args.steps, keep=True)
@@ -235,16 +253,6 @@ def main() -> None:
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
     timing = ctx.get_timing()
-    # one more clip with every kernel back to back on one stream: per-kernel durations free of the
-    # interference of the concurrent FFT stream (reported beside the timed-region figures)
-    ctx.set_concurrency(False)
-    ctx.get_timing(reset=True)
-    ctx.set_timing(True)
-    step(0)
-    torch.cuda.synchronize()
-    ctx.set_timing(False)
-    solo = ctx.get_timing(reset=True)
-    ctx.set_concurrency(True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=gather_device or "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -257,26 +265,22 @@ def main() -> None:
         fps = frames_total / dt
         ab = algorithmic_bytes(h, w, fh, fw)
         kt = timing["kernels"]
-        chunks = max(kt["gray"]["launches"], 1)  # the gray kernel runs once per chunk of frames
+        # frames per launch of the dominant group's kernels in the timed region (they run once per chunk)
+        chunks = max(max(kt[k]["launches"] for k in GROUPS[dom]), 1)
         frames_per_launch = timing["frames"] / chunks
-        solo_chunks = max(solo["kernels"]["gray"]["launches"], 1)
         # device time of each kernel group per chunk (sum of its kernels' HIP-event durations)
         group_ms = {g: sum(kt[k]["ms"] for k in ks) / chunks for g, ks in GROUPS.items()}
-        solo_ms = {g: sum(solo["kernels"][k]["ms"] for k in ks) / solo_chunks for g, ks in GROUPS.items()}
         solo_fpl = solo["frames"] / solo_chunks
         groups = {}
         for g in GROUPS:
-            if group_ms[g] <= 0 or ab[g] == 0:
+            if solo_ms[g] <= 0 or ab[g] == 0:
                 continue
-            ach = ab[g] * frames_per_launch / (group_ms[g] * 1e-3) / 1e9
-            ach_solo = ab[g] * solo_fpl / (solo_ms[g] * 1e-3) / 1e9 if solo_ms[g] > 0 else None
-            groups[g] = {"kernels": "+".join(k for k in GROUPS[g] if kt[k]["launches"]),
-                         "algorithmic_bytes_per_frame": ab[g], "avg_launch_ms": group_ms[g], "achieved": ach,
-                         "frac": ach / HBM_PEAK_GBS, "avg_launch_ms_serialized": solo_ms[g],
-                         "frac_serialized": ach_solo / HBM_PEAK_GBS if ach_solo else None}
-        # the dominant group is the one that takes longest with the device to itself (which group the stretch of
-        # running beside the other stream lands on varies from run to run)
-        dom = max(groups, key=lambda g: solo_ms[g])
+            ach = ab[g] * frames_per_launch / (group_ms[g] * 1e-3) / 1e9 if group_ms[g] > 0 else None
+            ach_solo = ab[g] * solo_fpl / (solo_ms[g] * 1e-3) / 1e9
+            groups[g] = {"kernels": "+".join(k for k in GROUPS[g] if solo["kernels"][k]["launches"]),
+                         "algorithmic_bytes_per_frame": ab[g], "avg_launch_ms": group_ms[g] if ach else None,
+                         "achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,
+                         "avg_launch_ms_serialized": solo_ms[g], "frac_serialized": ach_solo / HBM_PEAK_GBS}
         path_gbs = fps / world * ab["path"] / 1e9
         mt = measured_traffic(h, w)
         traffic = None
@@ -313,9 +317,10 @@ def main() -> None:
                 "frac_serialized": groups[dom]["frac_serialized"],
                 "algorithmic_bytes_per_frame": ab[dom], "frames_per_launch": frames_per_launch,
                 "avg_launch_ms": groups[dom]["avg_launch_ms"],
-                "note": "dominant group = the one with the longest serialized time; durations in the timed region "
-                        "include the stretch from running beside the other stream's kernels, *_serialized price the "
-                        "same group alone on the device",
+                "note": "dominant group = the one with the longest serialized time (one clip before the timed "
+                        "region, every kernel alone on the device with an event pair around it: *_serialized); in "
+                        "the timed region only the dominant group's kernels carry events (--time-all-kernels: all), "
+                        "and their durations include whatever runs beside them on the other stream",
                 "groups": groups,
                 "path": {"algorithmic_bytes_per_frame": ab["path"], "achieved": path_gbs,
                          "frac": path_gbs / HBM_PEAK_GBS},

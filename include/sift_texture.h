@@ -77,7 +77,7 @@ typedef struct stx_metrics {
 } stx_metrics;
 
 /* Accumulated device time per kernel family, measured with HIP events on the stream
- * the kernels run on (only while stx_set_timing(ctx, 1) is in effect). */
+ * the kernels run on (only while stx_set_timing is in effect, and only for the families it names). */
 #define STX_N_KERNELS 10
 typedef struct stx_timing {
     double ms[STX_N_KERNELS];       /* total elapsed milliseconds */
@@ -221,6 +221,9 @@ int stx_set_chunk_frames(stx_ctx* ctx, int frames);
 /* 1 (default): the FFT kernels run on a second stream beside the stencil / hysteresis kernels;
  * 0: every kernel runs back to back on one stream (clean per-kernel timings). */
 int stx_set_concurrency(stx_ctx* ctx, int enabled);
+/* enabled: 0 = off; 1 = every kernel family; otherwise a set of families, bit k+1 for family STX_K_<k> (an event
+ * pair around a kernel costs a few microseconds of device time between it and its neighbours on the stream: a caller
+ * that wants one family's durations without slowing the rest of the path names just that one). */
 int stx_set_timing(stx_ctx* ctx, int enabled);
 int stx_get_timing(stx_ctx* ctx, stx_timing* out, int reset);
 

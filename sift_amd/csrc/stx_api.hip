@@ -110,7 +110,11 @@ struct stx_ctx {
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
     bool concurrent_fft = true;
+    // the stencil pass converts BGR itself where it can; SIFT_TEXTURE_SEPARATE_GRAY=1 in the environment keeps the
+    // separate gray pass for every call (measurements, and tests that run both paths on one input)
+    bool fuse_gray = true;
     bool timing = false;
+    uint32_t timing_kinds = ~0u;       // bit k: launches of kernel family k are bracketed by events while timing is on
     stx_timing tacc;
     std::vector<hipEvent_t> event_pool;
 };
@@ -166,7 +170,7 @@ struct Span {
     bool on;
     hipStream_t st;
     Span(stx_ctx* c_, std::vector<TimedSpan>* dst_, int kind, int launches, hipStream_t stream = nullptr)
-        : c(c_), dst(dst_), on(c_->timing), st(stream ? stream : c_->stream) {
+        : c(c_), dst(dst_), on(c_->timing && ((c_->timing_kinds >> kind) & 1u)), st(stream ? stream : c_->stream) {
         if (!on) return;
         t.kind = kind;
         t.launches = launches;
@@ -437,23 +441,24 @@ void sync_all(stx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
 }
 
-int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g) {
+int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g, hipStream_t st = nullptr) {
     if (sl.passes + n > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
-    Span sp(c, &sl.spans, STX_K_HYST, n, c->stream);
+    if (!st) st = c->stream;
+    Span sp(c, &sl.spans, STX_K_HYST, n, st);
     for (int i = 0; i < n; ++i, ++sl.passes) {
         if (sl.passes < HYST_GRID_PASSES)
-            launch_hyst_pass(c->stream, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
+            launch_hyst_pass(st, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
                              (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
         else
-            launch_hyst_finish(c->stream, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
+            launch_hyst_finish(st, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
                                (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
     }
     sp.end();
     return STX_OK;
 }
 
-int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr) {
-    hipStream_t s = c->stream;
+int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr, hipStream_t s = nullptr) {
+    if (!s) s = c->stream;
     const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
     {
         Span sp(c, &sl.spans, STX_K_REDUCE, 1, s);
@@ -522,32 +527,48 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // FFT kernels of the chunk queued before it are done (under its hysteresis passes, which leave the device mostly
     // idle).  The big kernels of two chunks in each other's way cost more than the gaps they fill: 1.640 ms per
     // 150-frame 1080p clip with two clips in flight unchained, 1.602 ms chained, 1.65 ms one blocking call at a time.
-    if (c->prev_chunk && spre != s) {
-        HIPCHK(c, hipStreamWaitEvent(spre, c->prev_chunk->stencil_done, 0));
-        HIPCHK(c, hipStreamWaitEvent(spre, c->prev_chunk->fft_done, 0));
-    }
-    {
+    // The stencil pass converts the frames itself where it can (a separate gray pass is a fifth of a millisecond of
+    // HBM streaming per 150-frame 1080p clip, the conversion inside the stencil's tile loader a quarter of that);
+    // every kernel after it reads the plane it leaves behind.
+    const BgrSource bsrc = {bgr_dev, row_stride, frame_stride, p.gray_shift};
+    // (the Laplacian and the extended statistics read the plane's reflected frame, which only the gray pass writes)
+    const bool fused_gray = c->fuse_gray && !p.quality_stats && !pr.ext && stencil_reads_bgr(g, bsrc);
+    if (!fused_gray) {
+        if (c->prev_chunk && spre != s) {
+            HIPCHK(c, hipStreamWaitEvent(spre, c->prev_chunk->stencil_done, 0));
+            HIPCHK(c, hipStreamWaitEvent(spre, c->prev_chunk->fft_done, 0));
+        }
         Span sp(c, &sl.spans, STX_K_GRAY, 1, spre);
         launch_gray(spre, bgr_dev, row_stride, frame_stride, F, g, p.gray_shift, (uint8_t*)sl.gray.p);
         sp.end();
     }
-    HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
-    if (spre != s) HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));
-    // These clears sit between the gray pass and the stencil on purpose.  They do not depend on the gray plane, but
-    // queued ahead of the wait the stencil starts together with the FFT row pass, holds the wave slots, and the row
-    // pass (a persistent grid that needs half a SIMD's registers per wave) trickles in beside it: 1.79 ms per
-    // 150-frame 1080p clip against 1.75 ms when the row pass gets the 30 us head start the clears give it, runs by
-    // itself at its HBM-store bound, and the stencil then shares the device with the column pass.
-    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), s));
-    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), s));
+    // Clears.  The second half of the tile flags doubles as "this tile holds a strong pixel" between the stencil and
+    // the first hysteresis pass (the second pass is the first to write it as change flags).
+    // With a separate gray pass they sit between the gray pass and the stencil on purpose.  They do not depend on the
+    // gray plane, but queued ahead of the wait the stencil starts together with the FFT row pass, holds the wave
+    // slots, and the row pass (a persistent grid that needs half a SIMD's registers per wave) trickles in beside it:
+    // 1.79 ms per 150-frame 1080p clip against 1.75 ms when the row pass gets the 30 us head start the clears give
+    // it, runs by itself at its HBM-store bound, and the stencil then shares the device with the column pass.
+    // Without one they run on the otherwise idle first stream as soon as they are queued, under the chunk before.
+    hipStream_t side = c->concurrent_fft ? c->stream_fft : s;
+    const bool fused_flow = fused_gray && side != s;
+    hipStream_t sclr = fused_flow ? spre : s;
+    if (!fused_flow) {
+        HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
+        if (spre != s) HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));
+    }
+    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), sclr));
+    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), sclr));
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
     if (lbp81 && (rc = ensure_tie_tables(c, pr.off)) != STX_OK) return rc;
-    // the second half of the tile flags doubles as "this tile holds a strong pixel" between the stencil and the first
-    // hysteresis pass (the second pass is the first to write it as change flags)
-    HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, s));
+    HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, sclr));
+    if (fused_flow) {
+        HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
+        HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));
+    }
     {
         Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
-        launch_stencil(s, (const uint8_t*)sl.gray.p, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
+        launch_stencil(s, (uint8_t*)sl.gray.p, fused_gray ? &bsrc : nullptr, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
                        (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr,
                        (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words);
         sp.end();
@@ -577,13 +598,22 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         sp.end();
         if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
     }
-    // a fixed first batch of hysteresis passes (a pass exits at once when the one before it
-    // changed nothing); finish_chunk() checks the last counter and only then adds more
-    if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
-    // The FFT pair only needs the gray plane: it runs on a second stream, concurrently with the
-    // stencil and hysteresis kernels (measured 12 % less wall time per clip than one stream).
+    // A fixed first batch of hysteresis passes (a pass exits at once when the one before it changed nothing);
+    // finish_chunk() checks the last counter and only then adds more.
+    // With a separate gray pass the FFT pair only needs the gray plane: it runs on a second stream, beside the
+    // stencil and hysteresis kernels, and the first stream collects the results.  When the stencil pass makes the
+    // gray plane, the FFT pair follows it on the same stream, so that the big kernels of this chunk and the next run
+    // back to back with no event between them; the hysteresis passes, which leave the device mostly idle, run on the
+    // second stream beside the row pass, and so does the collection of the results, beside the next chunk's stencil
+    // pass.
+    if (fused_flow) {
+        HIPCHK(c, hipStreamWaitEvent(side, sl.stencil_done, 0));
+        if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g, side)) != STX_OK) return rc;
+    } else {
+        if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
+    }
     {
-        hipStream_t sf = c->concurrent_fft ? c->stream_fft : s;
+        hipStream_t sf = fused_gray ? s : side;
         if (sf != s) HIPCHK(c, hipStreamWaitEvent(sf, sl.gray_ready, 0));
         {
             Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1, sf);
@@ -596,13 +626,13 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
                             (FftPart*)sl.part.p, fft_small_threshold(g.fh, g.fw));
             sp.end();
         }
-        if (sf != s) {
+        if (side != s) {
             HIPCHK(c, hipEventRecord(sl.fft_done, sf));
-            HIPCHK(c, hipStreamWaitEvent(s, sl.fft_done, 0));
+            HIPCHK(c, hipStreamWaitEvent(fused_flow ? side : s, sl.fft_done, 0));
         }
     }
     c->prev_chunk = &sl;
-    return queue_results(c, sl, pr);
+    return queue_results(c, sl, pr, fused_flow ? side : s);
 }
 
 // Means, deviations and ratios of the extended statistics from their exact integer sums.
@@ -806,6 +836,10 @@ int stx_create(int device_id, stx_ctx** out) {
     if (!c) return STX_ERR_NOMEM;
     c->device = device_id;
     memset(&c->tacc, 0, sizeof(c->tacc));
+    {
+        const char* sep = getenv("SIFT_TEXTURE_SEPARATE_GRAY");
+        c->fuse_gray = !(sep && sep[0] && sep[0] != '0');
+    }
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
     if (e == hipSuccess) { step = "hipStreamCreateWithFlags"; e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); }
@@ -1397,6 +1431,7 @@ int stx_set_concurrency(stx_ctx* c, int enabled) {
 int stx_set_timing(stx_ctx* c, int enabled) {
     if (!c) return STX_ERR_INVALID;
     c->timing = enabled != 0;
+    c->timing_kinds = (enabled & 1) ? ~0u : ((uint32_t)enabled >> 1);
     return STX_OK;
 }
 int stx_get_timing(stx_ctx* c, stx_timing* out, int reset) {

@@ -93,7 +93,18 @@ struct FftPart {
 void launch_gray(hipStream_t s, const uint8_t* bgr, int64_t row_stride, int64_t frame_stride, int n_frames,
                  const Geom& g, int shift, uint8_t* gray);
 
-void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
+// Where the stencil pass converts the frames itself instead of reading a finished gray plane.
+struct BgrSource {
+    const uint8_t* bgr;  // device, packed BGR
+    int64_t row_stride, frame_stride;
+    int shift;           // 14 or 15: fixed-point precision of the conversion
+};
+// True if the stencil pass can read these frames directly: its loader takes four pixels (twelve bytes) per lane and
+// mirrors the border with one reflection.
+bool stencil_reads_bgr(const Geom& g, const BgrSource& src);
+// gray: the padded plane.  With src == nullptr it is the pass's input; otherwise the pass converts the BGR frames
+// while it loads its tiles and writes the pixels of the plane (not its reflected frame) for the kernels after it.
+void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag);
 // Tables the (P=8,R=1) LBP uses for flat neighbourhoods (built on the host once per context and copied to the

@@ -1,4 +1,6 @@
-// Fused stencil pass over the padded gray plane: one LDS tile feeds
+// Fused stencil pass: one LDS tile of gray levels -- read from the padded gray plane, or converted from the BGR frame
+// on the way in (cv2.cvtColor(BGR2GRAY), passive_checker.py:100; the gray plane is then this pass's by-product for the
+// FFT) -- feeds
 //   * uniform LBP (P=8, R=1) codes -> 10-bin histogram      (passive_checker.py:103-104)
 //   * 3x3 high-pass, saturated -> sum and sum of squares     (:107-108)
 //   * 5x5 Gaussian residual |gray - blur| -> sum             (:111-113)
@@ -153,6 +155,12 @@ __device__ __forceinline__ uint8_t code_of(uint2 e) { return (uint8_t)(e.x ? (__
 
 struct StencilArgs {
     const uint8_t* gray;
+    // FROM_BGR: the frames themselves, the conversion weights scaled to a 16-bit shift and split into high and low
+    // bytes (B, G, R in bytes 0..2), and the plane the converted pixels are written to
+    const uint8_t* bgr;
+    int64_t row_stride, frame_stride;
+    uint32_t w_hi, w_lo;
+    uint8_t* gray_w;
     int H, W, gpitch, grows, bm_words;
     uint32_t low2, high2;                   // thresholds, clamped to [-1, 4095], in both halves
     double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
@@ -662,7 +670,96 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     }
 }
 
-template <bool DO_LBP, bool CODES>
+struct __attribute__((aligned(4))) Bgr4 {
+    uint32_t a, b, c;  // 12 bytes = four BGR pixels
+};
+
+// Four BGR pixels to four gray bytes, as cv2.cvtColor's fixed-point path: (B wB + G wG + R wR + half) >> shift.  The
+// weights come scaled so that the shift is 16 and split into bytes, w = 256 hi + lo, which makes a pixel two four-byte
+// dot products: a pixel's three bytes sit in one word after at most one byte alignment, and the fourth byte meets a
+// zero weight.  floor((256 H + L) / 65536) = floor((H + floor(L / 256)) / 256): the low product, shifted, is the
+// accumulator of the high one, and the gray level is byte 1 of the result.
+__device__ __forceinline__ uint32_t gray4(Bgr4 v, uint32_t w_hi, uint32_t w_lo) {
+    // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3
+    const uint32_t p1 = __builtin_amdgcn_alignbyte(v.b, v.a, 3), p2 = __builtin_amdgcn_alignbyte(v.c, v.b, 2);
+    auto px = [](uint32_t p, uint32_t hi, uint32_t lo) {
+        return __builtin_amdgcn_udot4(p, hi, __builtin_amdgcn_udot4(p, lo, 32768u, false) >> 8, false);
+    };
+    const uint32_t s0 = px(v.a, w_hi, w_lo), s1 = px(p1, w_hi, w_lo), s2 = px(p2, w_hi, w_lo),
+                   s3 = px(v.c, w_hi << 8, w_lo << 8);
+    return perm(s1, s0, 0x0c0c0501u) | perm(s3, s2, 0x05010c0cu);
+}
+
+// The stencil tile straight from the BGR frame: LROWS x LDW words of four pixels, converted on the way in, each word
+// from one 12-byte load.  A thread keeps one word column and walks down the rows, LD_ROWS apart (no division;
+// everything that depends on the column is worked out once).  Rows above and below the image and the word left of
+// column 0 / right of column W-1 hold BORDER_REFLECT_101 copies: a mirrored row is another row's load; a mirrored word
+// is its neighbour's load with the bytes picked in reverse after the conversion ((-2,-1) = (2,1), (W,W+1) =
+// (W-2,W-3); further out nothing reads).  Words inside the image go to the gray plane as well, after the tile is
+// complete: a load issued behind a store waits for it.
+// Loads and stores are buffer instructions: the address is a scalar base (the frame), a scalar offset (the pass's
+// first row) and one per-thread offset that does not change from pass to pass, so an access costs no address
+// arithmetic, and an offset past the end of the buffer turns a store into nothing (how a thread whose word is not
+// part of the plane "skips" it).
+// ROWS_INSIDE: every tile row is an image row (otherwise a row's offset is mirrored per lane).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+constexpr int BUFFER_WORD3 = 0x00020000;       // raw buffer of 32-bit elements
+constexpr uint32_t OFF_NOWHERE = 0x7FFF0000u;  // past the end of any buffer here (their sizes stay below 2^31)
+template <bool ROWS_INSIDE>
+__device__ __forceinline__ void load_tile_bgr(const StencilArgs& a, uint32_t* tile, int frame, int x0, int y0, int tid) {
+    constexpr int LD_ROWS = 256 / LDW;                       // rows per pass (7)
+    constexpr int PASSES = (LROWS + LD_ROWS - 1) / LD_ROWS;  // 19
+    constexpr int BATCH = ROWS_INSIDE ? PASSES : 10;
+    const int r0 = tid / LDW, d = tid - r0 * LDW;
+    if (r0 >= LD_ROWS) return;
+    const uint32_t rs = (uint32_t)a.row_stride;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.bgr) + (int64_t)frame * a.frame_stride, 0, (int)((uint32_t)(a.H - 1) * rs + 3u * (uint32_t)a.W), BUFFER_WORD3);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        a.gray_w + (int64_t)frame * a.grows * a.gpitch, 0, a.grows * a.gpitch, BUFFER_WORD3);
+    const int xs = x0 - 4 + 4 * d;
+    const uint32_t xbyte = 3u * (uint32_t)(xs < 0 ? 0 : (xs >= a.W ? a.W - 4 : xs));
+    const uint32_t bsel = xs < 0 ? 0x01020000u : (xs >= a.W ? 0x00000102u : 0x03020100u);
+    const int ytop = y0 - 2 + r0, ymir = 2 * a.H - 2;
+    const uint32_t voff = __umul24((uint32_t)r0, rs) + xbyte;
+    uint32_t gq[PASSES];
+#pragma unroll
+    for (int kb = 0; kb < PASSES; kb += BATCH) {
+        u32x3 v[BATCH];  // the loads of a batch are issued before its first conversion
+#pragma unroll
+        for (int k = kb; k < kb + BATCH && k < PASSES; ++k) {
+            if (ROWS_INSIDE) {
+                // (the last pass runs past the tile for some threads: an image row or past the buffer, both harmless)
+                v[k - kb] = __builtin_amdgcn_raw_buffer_load_b96(src, (int)voff, (y0 - 2 + LD_ROWS * k) * (int)rs, 0);
+            } else {
+                int yy = ytop + LD_ROWS * k;
+                yy = yy < 0 ? -yy : yy;
+                const int ym = ymir - yy;
+                yy = yy < ym ? yy : ym;
+                yy = yy < 0 ? 0 : yy;  // rows far below the image: nothing reads them
+                v[k - kb] = __builtin_amdgcn_raw_buffer_load_b96(src, (int)(__umul24((uint32_t)yy, rs) + xbyte), 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = kb; k < kb + BATCH && k < PASSES; ++k) {
+            const Bgr4 q = {v[k - kb].x, v[k - kb].y, v[k - kb].z};
+            gq[k] = perm(0, gray4(q, a.w_hi, a.w_lo), bsel);
+            if (LD_ROWS * k + LD_ROWS <= LROWS || r0 + LD_ROWS * k < LROWS) tile[tid + LD_ROWS * LDW * k] = gq[k];
+        }
+    }
+    // plane row of tile row r is y0 + r (the tile starts two rows above y0, the plane two rows above the image)
+    const bool col_in = d >= 1 && d <= TILE_W / 4 && xs < a.W;
+    const uint32_t woff = col_in ? __umul24((uint32_t)r0, (uint32_t)a.gpitch) + (uint32_t)(xs + GRAY_XOFF) : OFF_NOWHERE;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+        const int row = r0 + LD_ROWS * k;
+        bool ok = (LD_ROWS * k >= 2 || row >= 2) && (LD_ROWS * k + LD_ROWS <= LROWS - 2 || row < LROWS - 2);
+        if (!ROWS_INSIDE) ok = ok && ytop + LD_ROWS * k < a.H;
+        __builtin_amdgcn_raw_buffer_store_b32(gq[k], dst, (int)(ok ? woff : OFF_NOWHERE), (y0 + LD_ROWS * k) * a.gpitch, 0);
+    }
+}
+
+template <bool DO_LBP, bool CODES, bool FROM_BGR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL_WAVES, STX_STENCIL_WAVES))) void stencil_kernel(StencilArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LROWS * LDW];
     __shared__ uint2 lut[LUT_ENTRIES];
@@ -678,8 +775,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
     // LPITCH = 8 * 16 + 8 bytes long: sixteen lanes per row, nine of them busy (eight 16-byte pieces and the tail),
     // sixteen rows per pass.  The index arithmetic is a shift and a mask; a flat loop over 32-bit words cost a
     // division per word and a tenth of the kernel's time.
-    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch + x0;
-    {
+    if (FROM_BGR) {
+        // block-uniform: every tile row is an image row (no mirrored rows, one address step from row to row)
+        if (y0 >= 2 && y0 + TILE_H + 2 <= a.H)
+            load_tile_bgr<true>(a, tile, frame, x0, y0, tid);
+        else
+            load_tile_bgr<false>(a, tile, frame, x0, y0, tid);
+    } else {
+        const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch + x0;
         const int lc = tid & 15;
         if (lc < 9) {
             constexpr int PASSES = (LROWS + 15) / 16;
@@ -785,10 +888,33 @@ void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_
             }
 }
 
-void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, bool do_lbp81,
+bool stencil_reads_bgr(const Geom& g, const BgrSource& src) {
+    const bool aligned4 = ((reinterpret_cast<uintptr_t>(src.bgr) | (uintptr_t)src.row_stride | (uintptr_t)src.frame_stride) & 3u) == 0;
+    // byte offsets inside a frame are computed in 32 bits
+    return aligned4 && (g.W & 3) == 0 && g.H >= 3 && src.row_stride > 0 && src.row_stride * (int64_t)g.H < ((int64_t)1 << 31);
+}
+
+void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag) {
     StencilArgs a;
+    a.bgr = nullptr;
+    a.row_stride = a.frame_stride = 0;
+    a.w_hi = a.w_lo = 0;
+    a.gray_w = gray;
+    if (src) {
+        if (!stencil_reads_bgr(g, *src)) abort();
+        a.bgr = src->bgr;
+        a.row_stride = src->row_stride;
+        a.frame_stride = src->frame_stride;
+        // cv2's weights for B, G, R at 14 and at 15 fractional bits, scaled to 16
+        const uint32_t w[3] = {src->shift == 15 ? 3735u << 1 : 1868u << 2, src->shift == 15 ? 19235u << 1 : 9617u << 2,
+                               src->shift == 15 ? 9798u << 1 : 4899u << 2};
+        for (int k = 0; k < 3; ++k) {
+            a.w_hi |= (w[k] >> 8) << (8 * k);
+            a.w_lo |= (w[k] & 255u) << (8 * k);
+        }
+    }
     a.sflag = sflag;
     a.bm_tiles = g.bm_tiles;
     a.tie = tie_blob;
@@ -810,12 +936,19 @@ void launch_stencil(hipStream_t s, const uint8_t* gray, int n_frames, const Geom
     a.cand = reinterpret_cast<uint32_t*>(cand);
     a.codes = codes_out;
     dim3 grid(g.tiles_x, g.tiles_y, n_frames);
-    if (!do_lbp81)
-        hipLaunchKernelGGL((stencil_kernel<false, false>), grid, dim3(256), 0, s, a);
+    if (src) {
+        if (!do_lbp81)
+            hipLaunchKernelGGL((stencil_kernel<false, false, true>), grid, dim3(256), 0, s, a);
+        else if (codes_out)
+            hipLaunchKernelGGL((stencil_kernel<true, true, true>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((stencil_kernel<true, false, true>), grid, dim3(256), 0, s, a);
+    } else if (!do_lbp81)
+        hipLaunchKernelGGL((stencil_kernel<false, false, false>), grid, dim3(256), 0, s, a);
     else if (codes_out)
-        hipLaunchKernelGGL((stencil_kernel<true, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((stencil_kernel<true, true, false>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((stencil_kernel<true, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((stencil_kernel<true, false, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace stx

@@ -207,8 +207,12 @@ class TextureContext:
     def set_concurrency(self, on: bool):
         self._check(self.lib.stx_set_concurrency(self.handle, 1 if on else 0), "stx_set_concurrency")
 
-    def set_timing(self, on: bool):
-        self._check(self.lib.stx_set_timing(self.handle, 1 if on else 0), "stx_set_timing")
+    def set_timing(self, on: bool, kinds=None):
+        """Per-kernel HIP-event timing on or off; kinds = names of the kernel families to time (default: all)."""
+        v = 1 if on else 0
+        if on and kinds is not None:
+            v = sum(2 << _lib.KERNEL_NAMES.index(k) for k in kinds)
+        self._check(self.lib.stx_set_timing(self.handle, v), "stx_set_timing")
 
     def get_timing(self, reset: bool = False) -> dict:
         t = StxTiming()

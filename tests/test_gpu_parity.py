@@ -194,6 +194,45 @@ def test_params_fft_crop_gray14_thresholds(ctx, coracle):
     _check_record(r, coracle.analyze_frame(f, op), P=16)
 
 
+def test_gray_inside_stencil_pass_and_separate_gray_pass(ctx, coracle, monkeypatch):
+    """Widths that are a multiple of four take the stencil pass that converts BGR itself (no separate gray pass);
+    SIFT_TEXTURE_SEPARATE_GRAY=1 at context creation keeps the two passes apart.  Same results, both the oracle's,
+    at both fixed-point precisions of the conversion, around every tile / strip / border case of the tile loader."""
+    from sift_amd.texture import TextureContext
+    monkeypatch.setenv("SIFT_TEXTURE_SEPARATE_GRAY", "1")
+    sep = TextureContext(0)
+    monkeypatch.delenv("SIFT_TEXTURE_SEPARATE_GRAY")
+    try:
+        shapes = [(3, 4), (4, 4), (3, 8), (5, 12), (64, 64), (127, 124), (129, 132), (130, 256), (131, 260), (257, 128),
+                  (300, 392), (1080, 1920)]
+        for i, (h, w) in enumerate(shapes):
+            kind = KINDS[i % len(KINDS)]
+            f = synth_frame(kind, SEED, 70 + i, 0, h, w)
+            for shift in (14, 15):
+                p = ctx.default_params()
+                p.gray_shift = shift
+                op = coracle.default_params()
+                op.gray_shift = shift
+                m = coracle.analyze_frame(f, op)
+                a = ctx.analyze_frames([f], p)[0]
+                b = sep.analyze_frames([f], p)[0]
+                _check_record(a, m)
+                _check_record(b, m)
+                for k in O.METRIC_KEYS:
+                    assert getattr(a, k) == getattr(b, k), (k, h, w, shift)
+            if h * w <= 300 * 392:
+                ga, ca, ea = ctx.debug_planes(f)
+                gb, cb, eb = sep.debug_planes(f)
+                assert np.array_equal(ga, gb) and np.array_equal(ca, cb) and np.array_equal(ea, eb), (h, w)
+        # a batch whose frames differ, in one call
+        fr = [synth_frame(KINDS[j % len(KINDS)], SEED, 90 + j, j, 200, 264) for j in range(5)]
+        for a, b, f in zip(ctx.analyze_frames(fr), sep.analyze_frames(fr), fr):
+            _check_record(a, coracle.analyze_frame(f))
+            _check_record(b, coracle.analyze_frame(f))
+    finally:
+        sep.close()
+
+
 def test_odd_fft_sizes(ctx, coracle):
     # prime and mixed sizes exercise the generic butterfly: 17x23, 7*11=77, 2*3*5*7=210, 13
     for (h, w) in [(17, 23), (77, 13), (210, 66), (49, 121), (26, 34)]:

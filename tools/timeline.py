@@ -23,11 +23,13 @@ def main():
     clips = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]) for r in rows)
     gray = [e for e in ev if e[2] == "gray"]
+    if not gray:  # the stencil pass reads the frames itself: a clip starts with it
+        gray = [e for e in ev if e[2] == "stencil"]
     # the last clip of bench.py runs serialized on one stream; the `clips` before it are the timed, concurrent ones
     first, last = gray[-1 - clips][0], gray[-1][0]
     sel = [e for e in ev if first <= e[0] < last]
     t0 = sel[0][0]
-    print("concurrent clips (times in us from the first gray kernel)")
+    print("concurrent clips (times in us from the first kernel of a clip)")
     for s, e, n, q in sel:
         if n in ("fill", "copy", "reduce"):
             continue
