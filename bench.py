@@ -230,9 +230,10 @@ def main() -> None:
     # bracketed by events in the timed region: an event pair costs the stream a few microseconds on either side of
     # the kernel, which adds up over a chain of dependent kernels.
     ctx.set_concurrency(False)
+    step(0)  # untimed: the measured clip below starts on a busy device, like every clip of the timed region
     ctx.get_timing(reset=True)
     ctx.set_timing(True)
-    step(0)
+    step(1)
     torch.cuda.synchronize()
     ctx.set_timing(False)
     solo = ctx.get_timing(reset=True)

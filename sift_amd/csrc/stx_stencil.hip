@@ -748,7 +748,12 @@ __device__ __forceinline__ void load_tile_bgr(const StencilArgs& a, uint32_t* ti
         }
     }
     // plane row of tile row r is y0 + r (the tile starts two rows above y0, the plane two rows above the image)
-    const bool col_in = d >= 1 && d <= TILE_W / 4 && xs < a.W;
+    // Which words of a tile row go to the plane: words 0..31, i.e. the pixels x0-4 .. x0+123, which is one aligned
+    // 128-byte line of the plane (pixel x lives at byte x + 4) -- the tile's own 128 pixels would straddle two lines,
+    // and partly written lines cost the memory system read-modify-write cycles.  The neighbour to the right writes
+    // the pixels x0+124 .. x0+127 as its word 0; the last tile of a row has no such neighbour and writes word 32 too.
+    // (Word 0 of the first tile lands in the plane's left frame.)
+    const bool col_in = (d < TILE_W / 4 || (d == TILE_W / 4 && x0 + TILE_W >= a.W)) && xs < a.W;
     const uint32_t woff = col_in ? __umul24((uint32_t)r0, (uint32_t)a.gpitch) + (uint32_t)(xs + GRAY_XOFF) : OFF_NOWHERE;
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
