@@ -4,16 +4,18 @@ one pass) over tools/prof1.py, which analyses FRAMES 1080p frames per dispatch.
     python profiles/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames> <out.json>
 
 Both counters come in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so the reads of
-kernels whose loads are 12 bytes per lane or wider (gray, FFT rows prefetch aside, FFT cols) are doubled;
-narrow-load kernels (stencil tile fill, hysteresis, FFT rows byte/halfword loads) are left as counted,
-so their true read traffic lies between the raw and the doubled figure.
+kernels whose loads are 12 bytes per lane or wider (gray, the stencil pass that reads BGR frames, FFT rows
+prefetch aside, FFT cols) are doubled; narrow-load kernels (hysteresis, FFT rows byte/halfword loads) are left
+as counted, so their true read traffic lies between the raw and the doubled figure.
 """
 import collections
 import csv
 import json
 import sys
 
-GROUPS = (("gray_kernel", "gray", True), ("stencil_kernel", "stencil", False), ("lbp_generic", "lbp_generic", False),
+# (substring of the kernel name, group, loads are wide); the first match counts.  stencil_kernel<.., .., true> reads
+# the BGR frames with 12-byte loads, stencil_kernel<.., .., false> the gray plane with 16-byte loads
+GROUPS = (("gray_kernel", "gray", True), ("stencil_kernel", "stencil", True), ("lbp_generic", "lbp_generic", False),
           ("hyst_pass_kernel", "hysteresis", False), ("rows_kernel", "fft_rows", False), ("cols_kernel", "fft_cols", True),
           ("frame_reduce", "reduce", False))
 
@@ -28,6 +30,7 @@ def per_kernel(path, counter):
             if sub in r["Kernel_Name"]:
                 tot[name] += float(r["Counter_Value"])
                 disp[name].add(r["Dispatch_Id"])
+                break
     return tot, disp
 
 

@@ -161,7 +161,7 @@ struct StencilArgs {
     int64_t row_stride, frame_stride;
     uint32_t w_hi, w_lo;
     uint8_t* gray_w;
-    int H, W, gpitch, grows, bm_words;
+    int H, W, gpitch, grows, bm_words, tiles_x, tiles_y;
     uint32_t low2, high2;                   // thresholds, clamped to [-1, 4095], in both halves
     double rp_neg, rp_pos, cp_pos, cp_neg;  // the four non-integer sample offsets of (P=8,R=1)
     uint32_t* part;    // [frame][tiles][16]: 10 LBP bins, hp sum, hp sum of squares, |gray-blur| sum, gray sum
@@ -771,9 +771,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
     __shared__ uint16_t wq[4][DO_LBP ? QUEUE_ITEMS : 2];
     __shared__ uint32_t wpend[4][DO_LBP ? (WAVE_ROWS / BLOCK_ROWS) * 64 : 2];
     __shared__ uint32_t red[4][16];
-    const int frame = blockIdx.z;
-    const int x0 = blockIdx.x * TILE_W;
-    const int y0 = blockIdx.y * TILE_H;
+    // Workgroups go to the eight accelerator dies round-robin by their linear number, and each die has its own L2.
+    // Tiles are numbered row by row, frame by frame; workgroup L takes tile (L % 8) * N/8 + L / 8, so that a die
+    // works through one contiguous run of tiles: the halo rows and columns a tile shares with its neighbours, and
+    // the cache lines its row segments share with them, are fetched into one L2 once instead of into two.
+    uint32_t tileid;
+    {
+        const uint32_t L = blockIdx.x, N = gridDim.x, q = N >> 3, r = N & 7u, die = L & 7u;
+        tileid = die * q + (die < r ? die : r) + (L >> 3);
+    }
+    const uint32_t tiles_per_frame = (uint32_t)(a.tiles_x * a.tiles_y);
+    const int frame = (int)(tileid / tiles_per_frame);
+    const uint32_t tin = tileid - (uint32_t)frame * tiles_per_frame;
+    const int tyi = (int)(tin / (uint32_t)a.tiles_x), txi = (int)(tin - (uint32_t)tyi * (uint32_t)a.tiles_x);
+    const int x0 = txi * TILE_W;
+    const int y0 = tyi * TILE_H;
     const int tid = threadIdx.x;
 
     // Tile rows start 64-byte aligned in the padded plane (x0 is a multiple of 128, the pitch of 64) and are
@@ -856,8 +868,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
     // per-tile partial sums, one slot per tile: no atomics, summed in a fixed order later
     if (tid < 16) {
         const uint32_t v = tid < 14 ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0u;
-        const int64_t tileid = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.part[tileid * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
+        a.part[(int64_t)tileid * 16 + tid] = (tid < 10 && !DO_LBP) ? 0u : v;
     }
 }
 
@@ -925,6 +936,7 @@ void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_fr
     a.tie = tie_blob;
     a.gray = gray;
     a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.bm_words = g.bm_words;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound
     const uint32_t lo = (uint32_t)(low < -1 ? -1 : (low > 4095 ? 4095 : low)) & 0xFFFFu;
     const uint32_t hi = (uint32_t)(high < -1 ? -1 : (high > 4095 ? 4095 : high)) & 0xFFFFu;
@@ -940,7 +952,8 @@ void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_fr
     a.strong = reinterpret_cast<uint32_t*>(strong);
     a.cand = reinterpret_cast<uint32_t*>(cand);
     a.codes = codes_out;
-    dim3 grid(g.tiles_x, g.tiles_y, n_frames);
+    if ((int64_t)g.tiles_x * g.tiles_y * n_frames > 0x7FFFFFFF) abort();
+    dim3 grid((unsigned)(g.tiles_x * g.tiles_y * n_frames), 1, 1);
     if (src) {
         if (!do_lbp81)
             hipLaunchKernelGGL((stencil_kernel<false, false, true>), grid, dim3(256), 0, s, a);
