@@ -1,4 +1,4 @@
-"""Timeline of one rocprofv3 --kernel-trace run of bench.py: for the last blocking clips, when each kernel ran,
+"""Timeline of one rocprofv3 --kernel-trace run of bench.py: for the last clips of the timed region, when each kernel ran,
 what ran beside it, and how busy the device was.
 
     python tools/timeline.py <kernel_trace.csv> [clips]
@@ -25,7 +25,8 @@ def main():
     gray = [e for e in ev if e[2] == "gray"]
     if not gray:  # the stencil pass reads the frames itself: a clip starts with it
         gray = [e for e in ev if e[2] == "stencil"]
-    # the last clip of bench.py runs serialized on one stream; the `clips` before it are the timed, concurrent ones
+    # the timed clips are the last ones bench.py runs (its serialized clips come before the warm-up): the window
+    # runs from the start of the clip `clips` + 1 from the end to the start of the last one
     first, last = gray[-1 - clips][0], gray[-1][0]
     sel = [e for e in ev if first <= e[0] < last]
     t0 = sel[0][0]
@@ -52,9 +53,6 @@ def main():
     print(f"per clip: {span / clips:.1f} us wall, {busy / 1e3 / clips:.1f} us with at least one kernel running, "
           f"{(span - busy / 1e3) / clips:.1f} us idle (host between blocking calls)")
     print("kernel time per clip (us):", {k: round(v / clips, 1) for k, v in sorted(tot.items())})
-    sel = [e for e in ev if e[0] >= last]
-    print("serialized clip (one stream):", {n: round(sum((e - s) for s, e, m, _ in sel if m == n) / 1e3, 1)
-                                           for n in sorted({m for _, _, m, _ in sel})})
 
 
 if __name__ == "__main__":
