@@ -531,8 +531,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // HBM streaming per 150-frame 1080p clip, the conversion inside the stencil's tile loader a quarter of that);
     // every kernel after it reads the plane it leaves behind.
     const BgrSource bsrc = {bgr_dev, row_stride, frame_stride, p.gray_shift};
-    // (the Laplacian and the extended statistics read the plane's reflected frame, which only the gray pass writes)
-    const bool fused_gray = c->fuse_gray && !p.quality_stats && !pr.ext && stencil_reads_bgr(g, bsrc);
+    const bool fused_gray = c->fuse_gray && stencil_reads_bgr(g, bsrc);
     if (!fused_gray) {
         if (c->prev_chunk && spre != s) {
             HIPCHK(c, hipStreamWaitEvent(spre, c->prev_chunk->stencil_done, 0));

@@ -103,7 +103,7 @@ struct BgrSource {
 // mirrors the border with one reflection.
 bool stencil_reads_bgr(const Geom& g, const BgrSource& src);
 // gray: the padded plane.  With src == nullptr it is the pass's input; otherwise the pass converts the BGR frames
-// while it loads its tiles and writes the pixels of the plane (not its reflected frame) for the kernels after it.
+// while it loads its tiles and writes the plane, reflected frame included, for the kernels after it.
 void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
                     unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag);

@@ -695,8 +695,8 @@ __device__ __forceinline__ uint32_t gray4(Bgr4 v, uint32_t w_hi, uint32_t w_lo) 
 // everything that depends on the column is worked out once).  Rows above and below the image and the word left of
 // column 0 / right of column W-1 hold BORDER_REFLECT_101 copies: a mirrored row is another row's load; a mirrored word
 // is its neighbour's load with the bytes picked in reverse after the conversion ((-2,-1) = (2,1), (W,W+1) =
-// (W-2,W-3); further out nothing reads).  Words inside the image go to the gray plane as well, after the tile is
-// complete: a load issued behind a store waits for it.
+// (W-2,W-3); further out nothing reads).  The words go to the gray plane as well, after the tile is complete: a load
+// issued behind a store waits for it.
 // Loads and stores are buffer instructions: the address is a scalar base (the frame), a scalar offset (the pass's
 // first row) and one per-thread offset that does not change from pass to pass, so an access costs no address
 // arithmetic, and an offset past the end of the buffer turns a store into nothing (how a thread whose word is not
@@ -751,15 +751,22 @@ __device__ __forceinline__ void load_tile_bgr(const StencilArgs& a, uint32_t* ti
     // Which words of a tile row go to the plane: words 0..31, i.e. the pixels x0-4 .. x0+123, which is one aligned
     // 128-byte line of the plane (pixel x lives at byte x + 4) -- the tile's own 128 pixels would straddle two lines,
     // and partly written lines cost the memory system read-modify-write cycles.  The neighbour to the right writes
-    // the pixels x0+124 .. x0+127 as its word 0; the last tile of a row has no such neighbour and writes word 32 too.
-    // (Word 0 of the first tile lands in the plane's left frame.)
-    const bool col_in = (d < TILE_W / 4 || (d == TILE_W / 4 && x0 + TILE_W >= a.W)) && xs < a.W;
+    // the pixels x0+124 .. x0+127 as its word 0; the last tile of a row has no such neighbour and writes the rest of
+    // its words up to the one that holds the mirrored columns W, W+1.  Word 0 of the first tile holds the mirrored
+    // columns -2, -1; the first and the last tile row write their mirrored rows as well: the plane comes out with the
+    // same BORDER_REFLECT_101 frame the separate gray pass gives it.
+    const bool col_in = xs <= a.W && (d < TILE_W / 4 || x0 + TILE_W >= a.W);
     const uint32_t woff = col_in ? __umul24((uint32_t)r0, (uint32_t)a.gpitch) + (uint32_t)(xs + GRAY_XOFF) : OFF_NOWHERE;
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
         const int row = r0 + LD_ROWS * k;
-        bool ok = (LD_ROWS * k >= 2 || row >= 2) && (LD_ROWS * k + LD_ROWS <= LROWS - 2 || row < LROWS - 2);
-        if (!ROWS_INSIDE) ok = ok && ytop + LD_ROWS * k < a.H;
+        bool ok;
+        if (ROWS_INSIDE) {
+            ok = (LD_ROWS * k >= 2 || row >= 2) && (LD_ROWS * k + LD_ROWS <= LROWS - 2 || row < LROWS - 2);
+        } else {
+            const int yy = ytop + LD_ROWS * k;  // image row; H and H + 1 are the mirrored rows below the image
+            ok = (row >= 2 || y0 == 0) && row < LROWS && (yy < a.H ? row < LROWS - 2 : yy < a.H + 2);
+        }
         __builtin_amdgcn_raw_buffer_store_b32(gq[k], dst, (int)(ok ? woff : OFF_NOWHERE), (y0 + LD_ROWS * k) * a.gpitch, 0);
     }
 }

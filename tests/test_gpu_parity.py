@@ -220,6 +220,13 @@ def test_gray_inside_stencil_pass_and_separate_gray_pass(ctx, coracle, monkeypat
                 _check_record(b, m)
                 for k in O.METRIC_KEYS:
                     assert getattr(a, k) == getattr(b, k), (k, h, w, shift)
+            # the Laplacian of the optional quality pass reads the plane's mirrored frame
+            p = ctx.default_params()
+            p.quality_stats = 1
+            qa, qb = ctx.analyze_frames([f], p)[0], sep.analyze_frames([f], p)[0]
+            want = coracle.quality_sums(coracle.gray(f))
+            assert (qa.lap_sum, qa.lap_sumsq, qa.gray_sumsq) == want, (h, w)
+            assert (qb.lap_sum, qb.lap_sumsq, qb.gray_sumsq) == want, (h, w)
             if h * w <= 300 * 392:
                 ga, ca, ea = ctx.debug_planes(f)
                 gb, cb, eb = sep.debug_planes(f)
