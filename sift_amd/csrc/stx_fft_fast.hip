@@ -742,6 +742,17 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     // the block [N][cbw] is contiguous in global memory
     const float2* src = a.spec + ((int64_t)frame * a.nkb + kb) * (int64_t)N * cbw;
     bool first_pass_done = false;
+    // Plans of three passes whose first is fused with the load keep the table twiddles of the other two in registers,
+    // loaded here, ahead of the block: they arrive with it, and no pass waits on global memory afterwards.
+    constexpr bool REGTW = ColsDirect<P>::ok && P::R2 > 1 && P::R3 == 1;
+    TwRegs<REGTW ? (P::N / P::R1 + 63) / 64 : 1> tw1;
+    TwRegs<REGTW ? (P::N / P::R2 + 63) / 64 : 1> tw2;
+    if constexpr (REGTW) {
+        if (cbw >= 2) {
+            tw1 = load_pass_twiddles<P::N, P::R1, P::R0>(a.tw, tid & 63);
+            tw2 = load_pass_twiddles<P::N, P::R2, P::R0 * P::R1>(a.tw, tid & 63);
+        }
+    }
     if constexpr (ColsDirect<P>::ok) {
         if (cbw >= 2) {
             constexpr int R0 = P::R0, M0 = ColsDirect<P>::M0;
@@ -833,7 +844,15 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     sink.small = a.small;
     sink.dc_col = (k == 0);
     sink.dc_fix = sink.dc_col ? (float)a.gray0[(int64_t)frame * a.gstride] * (float)N * (float)a.fw : 0.f;
-    if constexpr (ColsDirect<P>::ok) {
+    if constexpr (REGTW) {
+        if (first_pass_done) {
+            StoreSink<P::SWZ> st{buf};
+            pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw1, t, st);
+            pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, tw2, t, sink);
+        } else {
+            transform_to<P>(buf, a.tw, t, sink);
+        }
+    } else if constexpr (ColsDirect<P>::ok) {
         if (first_pass_done) transform_tail_to<P>(buf, a.tw, t, sink);
         else transform_to<P>(buf, a.tw, t, sink);
     } else {
