@@ -298,7 +298,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 -> packed u16 stencils, 16.16 fixed-point LBP pre-decision with f64 tie-breaks, f32 FFT "
+            "dtype": "u8 -> packed u16 stencils, 16-bit integer LBP decision with f64 tie-breaks, f32 FFT "
                      "(f64 for frames with near-zero spectrum bins), f64 sums",
             "data": "synthetic",
             "world_size_seen": world,
