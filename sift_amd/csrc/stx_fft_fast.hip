@@ -896,7 +896,7 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     X(960, 15, 8, 8, 1, 64)    \
     X(1024, 16, 8, 8, 1, 64)   \
     X(1080, 9, 20, 6, 1, 64)   \
-    X(1280, 5, 16, 16, 1, 64)  \
+    X(1280, 5, 8, 8, 4, 64)   \
     X(1440, 9, 16, 10, 1, 64)  \
     X(1920, 15, 16, 8, 1, 64)  \
     X(2048, 16, 16, 8, 1, 64)  \
