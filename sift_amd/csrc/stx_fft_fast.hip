@@ -323,13 +323,13 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const float2* __r
     pass<N, R, NS, LPT, SWZ>(buf, g, t, sink);
 }
 // the table twiddles of a pass, loaded once
-template <int N, int R, int NS>
-__device__ __forceinline__ TwRegs<(N / R + 63) / 64> load_pass_twiddles(const float2* __restrict__ twg, int t) {
-    constexpr int M = N / R, ITER = (M + 63) / 64;
+template <int N, int R, int NS, int LPT = 64>
+__device__ __forceinline__ TwRegs<(N / R + LPT - 1) / LPT> load_pass_twiddles(const float2* __restrict__ twg, int t) {
+    constexpr int M = N / R, ITER = (M + LPT - 1) / LPT;
     TwRegs<ITER> r;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int j = t + it * 64;
+        const int j = t + it * LPT;
         r.v[it] = twg[(j < M ? j % NS : 0) * (N / (NS * R))];
     }
     return r;
@@ -529,8 +529,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[P::TPW * P::S];
     constexpr int N = P::N, LPT = P::LPT;
     constexpr bool PAIRS = (LPT == 64);  // fused last pass
-    constexpr bool PREFETCH = !DIRECT && (P::TPW == 1) && (N % 4 == 0);
-    constexpr int NL = DIRECT ? P::R0 : (PREFETCH ? (N / 4 + 63) / 64 : 1);  // loads per lane and row
+    constexpr bool PREFETCH = !DIRECT && (N % 4 == 0);
+    constexpr int NL = DIRECT ? P::R0 : (PREFETCH ? (N / 4 + LPT - 1) / LPT : 1);  // loads per lane and row
     constexpr int NP = (P::R3 > 1) ? 4 : (P::R2 > 1) ? 3 : (P::R1 > 1) ? 2 : 1;
     static_assert(!PAIRS || NP >= 2, "a fused first or last pass needs at least two passes");
     const int lane = threadIdx.x;
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         } else {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const int x4 = lane + 64 * i;
-                const bool inx = (NL * 64 == N / 4) || x4 < N / 4;
+                const int x4 = t + LPT * i;
+                const bool inx = (NL * LPT == N / 4) || x4 < N / 4;
                 ra_reg[i] = (ina && inx) ? reinterpret_cast<const uint32_t*>(pa)[x4] : 0u;
                 rb_reg[i] = (inb && inx) ? reinterpret_cast<const uint32_t*>(pa + a.gpitch)[x4] : 0u;
             }
@@ -591,6 +591,9 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
     [[maybe_unused]] const auto tw_last = load_pair_twiddles<P, PAIRS ? RL : P::N>(a.tw, t);
     [[maybe_unused]] const auto tw_p1 = load_pass_twiddles<P::N, (PAIRS && NP >= 3) ? P::R1 : P::N, P::R0>(a.tw, t);
     [[maybe_unused]] const auto tw_p2 = load_pass_twiddles<P::N, (PAIRS && NP == 4) ? P::R2 : P::N, P::R0 * P::R1>(a.tw, t);
+    // sub-wave transforms of two passes: the second pass's table twiddle (one per lane)
+    constexpr bool SUB2 = !PAIRS && NP == 2;
+    [[maybe_unused]] const auto tw_s1 = load_pass_twiddles<P::N, SUB2 ? P::R1 : P::N, P::R0, LPT>(a.tw, t);
 
     // Loads and stores retire through one in-order counter, so waiting for the prefetched rows at the
     // top of a unit would also wait for the previous unit's freshly issued stores.  The prefetch registers
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         if (!(DIRECT || (PREFETCH && aligned))) mcur = origin(frame)[0];
         const float m = (float)mcur;
         if constexpr (DIRECT || PREFETCH) {
-            if (!ina || !inb) {  // wave-uniform and rare: rows past the end of the frame transform as zeros
+            if (!ina || !inb) {  // rare (wave-uniform with one transform per wave): rows past the end of the frame transform as zeros
                 const uint32_t m4 = mcur * 0x01010101u;
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
@@ -632,8 +635,8 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
         } else if (PREFETCH && aligned) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const int x4 = lane + 64 * i;
-                if ((NL * 64 == N / 4) || x4 < N / 4) {
+                const int x4 = t + LPT * i;
+                if ((NL * LPT == N / 4) || x4 < N / 4) {
                     const uint32_t wa = ra_reg[i], wb = rb_reg[i];
                     float2 e[4];
 #pragma unroll
@@ -697,7 +700,14 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
                 last_pass_pairs<P, P::R3>(buf, tw_last, t, emit);
             }
         } else {
-            transform<P>(buf, a.tw, t);
+            if constexpr (SUB2) {
+                StoreSink<P::SWZ> st{buf};
+                wave_sync();  // the signal was stored by other lanes
+                pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
+                pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_s1, t, st);
+            } else {
+                transform<P>(buf, a.tw, t);
+            }
             settle_prefetch();
             // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
             for (int k = t; k <= N / 2; k += LPT) emit(k, buf[pad<P::SWZ>(k)], buf[pad<P::SWZ>(k ? N - k : 0)]);
@@ -747,6 +757,8 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     constexpr bool REGTW = ColsDirect<P>::ok && P::R2 > 1 && P::R3 == 1;
     TwRegs<REGTW ? (P::N / P::R1 + 63) / 64 : 1> tw1;
     TwRegs<REGTW ? (P::N / P::R2 + 63) / 64 : 1> tw2;
+    constexpr bool SUB2 = !ColsDirect<P>::ok && P::R1 > 1 && P::R2 == 1;
+    [[maybe_unused]] const auto tw_s1 = load_pass_twiddles<P::N, SUB2 ? P::R1 : P::N, P::R0, P::LPT>(a.tw, (tid & 63) % P::LPT);
     if constexpr (REGTW) {
         if (cbw >= 2) {
             tw1 = load_pass_twiddles<P::N, P::R1, P::R0>(a.tw, tid & 63);
@@ -855,6 +867,11 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     } else if constexpr (ColsDirect<P>::ok) {
         if (first_pass_done) transform_tail_to<P>(buf, a.tw, t, sink);
         else transform_to<P>(buf, a.tw, t, sink);
+    } else if constexpr (SUB2) {
+        StoreSink<P::SWZ> st{buf};
+        wave_sync();  // the signal was stored by other lanes
+        pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
+        pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_s1, t, sink);
     } else {
         transform_to<P>(buf, a.tw, t, sink);
     }
