@@ -316,10 +316,15 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         o.sxy = gx ^ gy;
         uint32_t m = o.ax + o.ay;  // at most 2040 per half
         if (BORDER) m &= (r >= 0 && r < H) ? vm : 0u;
+        // The rotations first: every lane of a rotation has a source, so no register has to hold a value for lanes
+        // without one, and the shifts after them can then write into the old halo registers, which are dead by then
+        // (the other way round each shift costs a register copy).
+        const int nextL = __builtin_amdgcn_mov_dpp(haloL16, 0x134, 0xf, 0xf, false);  // wave_rol:1, lane i takes lane i+1
+        const int nextR = __builtin_amdgcn_mov_dpp(haloR, 0x13C, 0xf, 0xf, false);    // wave_ror:1, lane i takes lane i-1
         const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(haloL16, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
         const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(haloR, (int)m, 0x130, 0xf, 0xf, false);    // wave_shl:1
-        haloL16 = __builtin_amdgcn_update_dpp(0, haloL16, 0x134, 0xf, 0xf, false);  // wave_rol:1, lane i takes lane i+1
-        haloR = __builtin_amdgcn_update_dpp(0, haloR, 0x13C, 0xf, 0xf, false);      // wave_ror:1, lane i takes lane i-1
+        haloL16 = nextL;
+        haloR = nextR;
         o.M = m;
         o.ML = __builtin_amdgcn_alignbit(m, mp, 16);
         o.MR = __builtin_amdgcn_alignbit(mn, m, 16);
