@@ -75,6 +75,13 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t c) {  // a*K + c
 }
 // a*k + c per half with the multiplier in a register (constants above 64 cannot be inline operands)
 __device__ __forceinline__ uint32_t pk_mad_r(uint32_t a, uint32_t k, uint32_t c) { return word(asU(a) * asU(k) + asU(c)); }
+// the same as one instruction whatever the multiplier is (left to itself the compiler turns a multiplication by a
+// power of two, or by minus one, into a shift and a subtraction: two instructions of the same cost each)
+__device__ __forceinline__ uint32_t pk_mad_op(uint32_t a, uint32_t k, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(k), "v"(c));
+    return d;
+}
 template <int K>
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a) {
     const us2 k = {(unsigned short)K, (unsigned short)K};
@@ -296,7 +303,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             const uint32_t q0 = pk_mul<29>(o.z0);
             o.rp = pk_mad_r(zp1, 0x00460046u, q0);  // 70
             o.rm = pk_mad_r(zm1, 0x00460046u, q0);
-            const uint32_t e = pk_mad_r(o.z0, 0xFF80FF80u, 0x80028002u);  // 0x8002 - 128 c per half
+            const uint32_t e = pk_mad_op(o.z0, 0xFF80FF80u, 0x80028002u);  // 0x8002 - 128 c per half
             o.gp = pk_mad<29>(zp1, e);
             o.gm = pk_mad<29>(zm1, e);
             o.zh0 = o.z0 | HH;
@@ -309,7 +316,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // magnitudes seen from the left / right neighbour columns: ML = (x-1, x), MR = (x+1, x+2).
     struct MagRow { uint32_t ML, M, MR, ax, ay, sxy; };
     auto mag_row = [&](int r, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t s0, uint32_t s2, MagRow& o) {
-        const uint32_t gx = word(asS(d1) + asS(d1) + (asS(d0) + asS(d2)));
+        const uint32_t gx = pk_mad<2>(d1, pk_add(d0, d2));  // 2 d1 + d0 + d2 (the low 16 bits do not care about signs)
         const uint32_t gy = pk_sub(s2, s0);
         o.ax = pk_abs(gx);
         o.ay = pk_abs(gy);
