@@ -104,6 +104,14 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return word(__builtin_elementwise_min(asU(a), asU(b))); }
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+// v_bfi_b32 with a constant mask held in a scalar register, as written (the compiler prefers a shift, an and with a
+// literal and a share of a three-way or: two and a third instructions for one)
+template <uint32_t MASK>
+__device__ __forceinline__ uint32_t bfi_lit(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(MASK), "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // |a.lo - b.lo| + |a.hi - b.hi| + acc on unsigned 16-bit halves
 __device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc) {
@@ -429,13 +437,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     const uint32_t f5 = rw[3].rm + rw[2].gm;  // (+.7,-.7)
                     const uint32_t f7 = rw[3].rp + rw[2].gp;  // (+.7,+.7)
                     uint32_t bits = (f1 >> 5) & 0x04000400u;
-                    bits = bfi(0x02000200u, f3 >> 6, bits);
-                    bits = bfi(0x01000100u, f5 >> 7, bits);
-                    bits = bfi(0x00800080u, f7 >> 8, bits);
-                    bits = bfi(0x00400040u, a0 >> 9, bits);
-                    bits = bfi(0x00200020u, a2 >> 10, bits);
-                    bits = bfi(0x00100010u, a4 >> 11, bits);
-                    bits = bfi(0x00080008u, a6 >> 12, bits);
+                    bits = bfi_lit<0x02000200u>(f3 >> 6, bits);
+                    bits = bfi_lit<0x01000100u>(f5 >> 7, bits);
+                    bits = bfi_lit<0x00800080u>(f7 >> 8, bits);
+                    bits = bfi_lit<0x00400040u>(a0 >> 9, bits);
+                    bits = bfi_lit<0x00200020u>(a2 >> 10, bits);
+                    bits = bfi_lit<0x00100010u>(a4 >> 11, bits);
+                    bits = bfi_lit<0x00080008u>(a6 >> 12, bits);
                     // undecided: 0x8000 <= f < 0x8005, i.e. subtracting 5 clears bit 15 (f is at least 0x82)
                     uint32_t und = (f1 ^ (f1 - TIE_BAND)) | (f3 ^ (f3 - TIE_BAND)) | (f5 ^ (f5 - TIE_BAND)) |
                                    (f7 ^ (f7 - TIE_BAND));
