@@ -362,7 +362,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // the second stage at most QUEUE_ITEMS / 64 = 8 more: the first half of the strip is set aside after its 16 rows.
     uint32_t hist_a = 0, hist_b = 0, hist_a0 = 0, hist_b0 = 0;
     uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
-    uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, newest row lowest, per half
+    uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, first row highest, per half
     uint32_t accS0 = 0, accC0 = 0;    // rows 0..15 of the strip
 
     auto count_pixel = [&](uint32_t idx, int y, int xx) {
@@ -403,6 +403,11 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             const uint32_t blk_off = wave_off + (uint32_t)(blk * BLOCK_ROWS * LPITCH);
             // pend holds the undecided flags of this block, row i at bit 15-i (low pixel) and 31-i (high pixel)
             uint32_t pend = 0;
+            // room for this block's Canny bits: row i goes to bit 7-i of each half, the block before moves up (a half
+            // holds at most eight bits here, so nothing crosses into the other half)
+            static_assert(BLOCK_ROWS == 8, "Canny bits are collected a byte per block");
+            accC <<= 8;
+            accS <<= 8;
 #pragma unroll
             for (int i = 0; i < BLOCK_ROWS; ++i) {
                 const int y = yb + i;
@@ -490,11 +495,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         nb = pk_add(nb, bfi(nothoriz, vert, 0xFFFFFFFFu));
                         const uint32_t kc = pk_sub(na, m) & pk_sub(nb, m) & nz;
                         const uint32_t ks = kc & pk_sub(a.high2, m);
-                        accC = pk_mad<2>(accC, pk_shr<15>(kc));
-                        accS = pk_mad<2>(accS, pk_shr<15>(ks));
-                    } else {  // no candidate in the row: the words just move on (a half holds at most 15 bits here)
-                        accC += accC;
-                        accS += accS;
+                        // the sign bits go straight to the row's place in the words (plain shifts and masks; a row
+                        // without candidates leaves the words alone)
+                        accC |= (kc >> (8 + i)) & (0x00800080u >> i);
+                        accS |= (ks >> (8 + i)) & (0x00800080u >> i);
                     }
                 }
                 // ---- slide down one row
