@@ -846,7 +846,10 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
             const double l = (double)lf;
             ls += l;
             ls2 += l * l;
-            if (__any(mag < small)) {  // rare on camera-like content: the wave skips it as a whole
+            if (__builtin_expect(__any(mag < small), 0)) {  // rare on camera-like content: the wave skips it as a whole
+                // (an empty volatile statement: without it the compiler turns this block into selects and computes the
+                // reciprocal, a quarter-rate instruction, for every bin)
+                asm volatile("");
                 const float r = mag < small ? __builtin_amdgcn_rcpf(mag + 1.0f) : 0.f;
                 t1 += r;
                 t2 += r * lf;
