@@ -258,6 +258,10 @@ __device__ __forceinline__ int pad(int i) {
 // One Stockham pass of radix R; NS = product of the radices already applied.
 // Where a pass puts its outputs: back into the LDS buffer, or (last pass of the column
 // transform) straight into a consumer, which saves one LDS write and one LDS read per element.
+// A sink that wants the R outputs of a butterfly together (indices o, o + ns, ...) declares it here.
+template <class Sink>
+struct TakesButterflies { static constexpr bool value = false; };
+
 template <bool SWZ>
 struct StoreSink {
     float2* buf;
@@ -309,8 +313,12 @@ __device__ __forceinline__ void pass(float2* __restrict__ buf, const TwS& twg, i
                 }
                 Dft<R>::run(v[it]);
                 const int o = (j - k) * R + k;
+                if constexpr (TakesButterflies<Sink>::value) {
+                    sink.template butterfly<R>(o, NS, v[it]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) sink(o + r * NS, v[it][r]);
+                    for (int r = 0; r < R; ++r) sink(o + r * NS, v[it][r]);
+                }
             }
         }
         wave_sync();  // the next phase reads what other lanes wrote
@@ -741,6 +749,59 @@ struct ColsDirect {
     static constexpr bool ok = P::TPW == 1 && P::R1 > 1 && P::R0 > 1 && P::R0 <= 10 && M0 <= 128;
 };
 
+// Where the column pass's last butterflies go: ln(|F| + 1) summed and summed squared, per lane.
+struct LogMagSink {
+    double ls = 0.0, ls2 = 0.0;
+    float t1 = 0.f, t2 = 0.f, e2 = 0.f;
+    float dc_fix, small;
+    bool dc_col;
+    __device__ __forceinline__ void operator()(int y, float2 v) {
+        float2 one[1] = {v};
+        butterfly<1>(y, 0, one);
+    }
+    // The R bins of one butterfly: magnitudes and logarithms of all of them in one straight run of instructions (the
+    // square root and the logarithm are quarter-rate and dependent; side by side they overlap), and one test for
+    // the rare near-zero bin per butterfly instead of one per bin.
+    template <int R>
+    __device__ __forceinline__ void butterfly(int y0, int ns, float2 (&v)[R]) {
+        float mag[R], lf[R];
+        float lo = 3.0e38f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float p = v[r].x * v[r].x + v[r].y * v[r].y;
+            e2 += p;  // the energy of gray - m: what the transform's rounding noise scales with
+            if (dc_col && y0 + r * ns == 0) {
+                const float x = v[r].x + dc_fix;
+                p = x * x + v[r].y * v[r].y;
+            }
+            // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
+            // the statistic; the sums stay in fp64 because the variance is a small difference
+            mag[r] = __builtin_amdgcn_sqrtf(p);
+            lf[r] = __builtin_amdgcn_logf(mag[r] + 1.0f) * 0.69314718055994530942f;
+            lo = fminf(lo, mag[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double l = (double)lf[r];
+            ls += l;
+            ls2 += l * l;
+        }
+        if (__builtin_expect(__any(lo < small), 0)) {  // rare on camera-like content: the wave skips it as a whole
+            // (an empty volatile statement: without it the compiler turns this block into selects and computes the
+            // reciprocal, a quarter-rate instruction, for every bin)
+            asm volatile("");
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float q = mag[r] < small ? __builtin_amdgcn_rcpf(mag[r] + 1.0f) : 0.f;
+                t1 += q;
+                t2 += q * lf[r];
+            }
+        }
+    }
+};
+template <>
+struct TakesButterflies<LogMagSink> { static constexpr bool value = true; };
+
 // blockDim.x = 64 * cbw / TPW ; dynamic LDS = cbw * S float2
 template <class P>
 __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
@@ -827,35 +888,7 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     float2* buf = dynlds + c * S;
     const int k = kb * cbw + c;
     // the last pass hands its outputs straight to the log-magnitude reduction
-    struct LogMagSink {
-        double ls = 0.0, ls2 = 0.0;
-        float t1 = 0.f, t2 = 0.f, e2 = 0.f;
-        float dc_fix, small;
-        bool dc_col;
-        __device__ __forceinline__ void operator()(int y, float2 v) {
-            float p = v.x * v.x + v.y * v.y;
-            e2 += p;  // the energy of gray - m: what the transform's rounding noise scales with
-            if (dc_col && y == 0) {
-                v.x += dc_fix;
-                p = v.x * v.x + v.y * v.y;
-            }
-            // hardware sqrt / log2 (1 ulp each): errors of 1e-7 per bin, far inside the 1e-4 budget of
-            // the statistic; the sums stay in fp64 because the variance is a small difference
-            const float mag = __builtin_amdgcn_sqrtf(p);
-            const float lf = __builtin_amdgcn_logf(mag + 1.0f) * 0.69314718055994530942f;
-            const double l = (double)lf;
-            ls += l;
-            ls2 += l * l;
-            if (__builtin_expect(__any(mag < small), 0)) {  // rare on camera-like content: the wave skips it as a whole
-                // (an empty volatile statement: without it the compiler turns this block into selects and computes the
-                // reciprocal, a quarter-rate instruction, for every bin)
-                asm volatile("");
-                const float r = mag < small ? __builtin_amdgcn_rcpf(mag + 1.0f) : 0.f;
-                t1 += r;
-                t2 += r * lf;
-            }
-        }
-    } sink;
+    LogMagSink sink;
     sink.small = a.small;
     sink.dc_col = (k == 0);
     sink.dc_fix = sink.dc_col ? (float)a.gray0[(int64_t)frame * a.gstride] * (float)N * (float)a.fw : 0.f;
