@@ -162,6 +162,22 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     // the undecided samples (bits of near) of pixel (y, xx) in skimage's bilinear_interpolation, operation by operation
     auto settle = [&](uint32_t bits, uint32_t near, int y, int xx) -> uint32_t {
         const double c = (double)(gl_tile[(y - y0 + halo) * lpitch + (xx - x0 + halo)] & 0xFFFFu);
+        if constexpr (RING) {
+            // which of the pixel's blended samples are too close to call: the row loop's arithmetic once more
+            const uint8_t* pr = reinterpret_cast<const uint8_t*>(gl_tile) + 4 * ((y - y0) * lpitch + (xx - x0));
+            const uint32_t init = a.margin - ((uint32_t)c << 16);
+            near = 0;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                near += near;
+                if (Ring<PT>::d1(p) != 0) {
+                    const uint32_t top = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::top(p));
+                    const uint32_t bot = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::bot(p));
+                    const uint32_t t = dot2(top, a.wtop[p], dot2(bot, a.wbot[p], init));
+                    near |= t < 2u * a.margin + 1u ? 1u : 0u;
+                }
+            }
+        }
         while (near != 0) {
             const int b = __ffs(near) - 1;
             near &= near - 1;
@@ -193,6 +209,10 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
         const uint32_t c = gl_tile[pa] & 0xFFFFu;
         const uint32_t init = a.margin - (c << 16);
         uint32_t signs = 0, near = 0;  // sample p at bit P-1-p
+        // RING: the smallest t of the row's blended samples instead of a flag per sample (one v_min3 per two samples
+        // against a compare, a select and an or per sample); which samples of an undecided pixel are the undecided
+        // ones is worked out again when the pixel is settled
+        uint32_t tmin = 0xFFFFFFFFu;
         auto sample = [&](int p) {
             // t = (sample - centre) + margin in 1/65536 gray levels
             uint32_t top, bot;
@@ -201,10 +221,13 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
                 if (Ring<PT>::d1(p) == 0) {
                     // the sample is a pixel: one read, one shift-and-add, never undecided
                     signs = __builtin_amdgcn_alignbit(signs, (top << 16) + init, 31);
-                    near = near + near;
                     return;
                 }
                 bot = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring<PT>::bot(p));
+                const uint32_t t = dot2(top, a.wtop[p], dot2(bot, a.wbot[p], init));
+                signs = __builtin_amdgcn_alignbit(signs, t, 31);
+                tmin = tmin < t ? tmin : t;
+                return;
             } else {
                 top = *reinterpret_cast<const uint32_t*>(pb + a.otop[p]);
                 bot = *reinterpret_cast<const uint32_t*>(pb + a.obot[p]);
@@ -223,7 +246,8 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
         }
         const uint32_t bits = ~signs & pmask;  // LBP bit = sample >= centre
         const bool valid = x < a.W;
-        const bool und = valid && near != 0;
+        // 0 <= t <= 2*margin: too close to call
+        const bool und = valid && (RING ? tmin < 2u * a.margin + 1u : near != 0);
         if (valid && !und) count_pixel(bits, y, x);
         // Undecided pixels (ties, mostly) wait in the wave's queue for the end of the strip, where any lane takes
         // any entry: the fp64 replay then costs ceil(queued / 64) rounds instead of the worst lane's count per row.
