@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict
                                                        int high, unsigned long long* __restrict__ part) {
     __shared__ unsigned long long red[4][X_STATS];
     const int frame = blockIdx.z;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row offsets stay scalar
     const int x = blockIdx.x * 64 + lane;
     const uint8_t* gp = gray + (int64_t)frame * grows * gpitch + (int64_t)GRAY_YOFF * gpitch + GRAY_XOFF;
     uint32_t v[X_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -32,17 +33,31 @@ __global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict
     if (x < W && y0 < H) {
         const int xl = x > 0 ? x - 1 : 0, xr = x + 1 < W ? x + 1 : W - 1;
         const bool xedge = (x & 7) == 0;
-        auto row = [&](int y, int& l, int& m, int& r) {
-            const uint8_t* p = gp + (int64_t)(y < 0 ? 0 : (y < H ? y : H - 1)) * gpitch;
-            l = p[xl]; m = p[x]; r = p[xr];
-        };
-        int a, b, c, d, e, f, g, h, k;
-        row(y0 - 1, a, b, c);
-        row(y0, d, e, f);
+        // every byte of the strip first (three columns of X_ROWS + 2 rows): the loads are all in flight together
+        // and the strip waits for memory once, not once per row
+        // (buffer loads: the row is a scalar offset, clamped on the scalar side, the column a per-lane offset that
+        // never changes -- no address arithmetic per load)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(gp), 0, (H - 1) * gpitch + W, 0x00020000);
+        uint8_t pl[X_ROWS + 2], pm[X_ROWS + 2], pr[X_ROWS + 2];
+#pragma unroll
+        for (int i = 0; i < X_ROWS + 2; ++i) {
+            const int y = y0 - 1 + i;
+            const int ro = (y < 0 ? 0 : (y < H ? y : H - 1)) * gpitch;
+            pl[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, xl, ro, 0);
+            pm[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, x, ro, 0);
+            pr[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, xr, ro, 0);
+        }
+        // which sum a difference belongs to never changes for a lane (columns) or is known when the loop is unrolled
+        // (rows: y0 is a multiple of 8): masks and fixed accumulators, no indexed register array
+        static_assert(X_ROWS % 8 == 0, "row boundaries by the unrolled index");
+        const uint32_t in_h = x > 0 ? 0xFFFFFFFFu : 0u, on_h = (x > 0 && xedge) ? 0xFFFFFFFFu : 0u;
+        uint32_t h_all = 0, h_edge = 0;
+        int a = pl[0], b = pm[0], c = pr[0], d = pl[1], e = pm[1], f = pr[1], g, h, k;
 #pragma unroll
         for (int i = 0; i < X_ROWS; ++i) {
             const int y = y0 + i;
-            row(y + 1, g, h, k);
+            g = pl[i + 2]; h = pm[i + 2]; k = pr[i + 2];
             if (y < H) {
                 const int gx = (c + 2 * f + k) - (a + 2 * d + g);
                 const int gy = (g + 2 * h + k) - (a + 2 * b + c);
@@ -50,12 +65,16 @@ __global__ __launch_bounds__(256) void extended_kernel(const uint8_t* __restrict
                 v[0] += (uint32_t)mag;
                 v[1] += (uint32_t)(mag * mag);
                 v[2] += mag > high ? 1u : 0u;
-                if (x > 0) v[xedge ? 3 : 4] += (uint32_t)abs(e - d);
-                if (y > 0) v[(y & 7) == 0 ? 5 : 6] += (uint32_t)abs(e - b);
+                const uint32_t dh = (uint32_t)abs(e - d);
+                h_all += dh & in_h;
+                h_edge += dh & on_h;
+                if (y > 0) v[(i & 7) == 0 ? 5 : 6] += (uint32_t)abs(e - b);
             }
             a = d; b = e; c = f;
             d = g; e = h; f = k;
         }
+        v[3] = h_edge;
+        v[4] = h_all - h_edge;
     }
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
