@@ -35,7 +35,9 @@ def test_extended_sums_known_answers():
     assert np_extended_sums(img)["block_sums"] == [0, 8 * 2 * 10, 0, 0]
 
 
-GPU_SIZES = [(64, 64), (97, 131), (1, 1), (1, 40), (33, 1), (8, 8), (9, 17), (240, 320), (300, 390)]
+GPU_SIZES = [(64, 64), (97, 131), (1, 1), (1, 40), (33, 1), (8, 8), (9, 17), (240, 320), (300, 390),
+             # around the 256 columns of a wave and the four pixels of a lane in the Sobel / blockiness pass
+             (5, 255), (5, 256), (5, 257), (20, 258), (17, 259), (40, 513), (3, 2), (2, 3), (70, 5), (66, 6), (65, 7)]
 
 
 @pytest.mark.gpu
