@@ -205,7 +205,12 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
         if (y >= a.H) break;
         const int pa = (halo + wv * GL_ROWS + i) * lpitch + halo + lane;
         const uint8_t* pb = reinterpret_cast<const uint8_t*>(gl_tile) + 4 * pa;
-        const uint8_t* pr = pb - 4 * (halo * lpitch + halo);  // RING: every cell offset is non-negative from here
+        // RING: every cell offset is non-negative from here, i.e. fits the immediate offset of an LDS read.  The byte
+        // offset passes through an empty asm statement so that the compiler keeps this base and does not re-base the
+        // reads on another register, which costs an address addition for every read that then lies below it.
+        uint32_t pro = 4u * (uint32_t)((wv * GL_ROWS + i) * lpitch + lane);
+        asm volatile("" : "+v"(pro));
+        const uint8_t* pr = reinterpret_cast<const uint8_t*>(gl_tile) + pro;
         const uint32_t c = gl_tile[pa] & 0xFFFFu;
         const uint32_t init = a.margin - (c << 16);
         uint32_t signs = 0, near = 0;  // sample p at bit P-1-p
