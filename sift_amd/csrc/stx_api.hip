@@ -818,6 +818,10 @@ void stx_default_params(stx_params* p) {
 
 static thread_local std::string g_create_err = "null context";
 
+// events that only order this context's own streams on the device: no timing, and a release at device scope (the
+// data they guard is read by kernels, never by the host)
+static const unsigned INNER_EVENT = hipEventDisableTiming | hipEventReleaseToDevice;
+
 int stx_create(int device_id, stx_ctx** out) {
     if (!out) return STX_ERR_INVALID;
     *out = nullptr;
@@ -852,9 +856,9 @@ int stx_create(int device_id, stx_ctx** out) {
             step = "hipEventCreate";
             e = hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].gray_ready, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].fft_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].stencil_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].gray_ready, INNER_EVENT);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].fft_done, INNER_EVENT);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].stencil_done, INNER_EVENT);
     }
     if (e == hipSuccess) { step = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; e = fft_set_lds_limits(); }
     // the allocation-free entry point: this GPU's copy of the scratch array, result and twiddle staging, events
@@ -875,9 +879,9 @@ int stx_create(int device_id, stx_ctx** out) {
         e = hipHostMalloc(&c->na_stage, (sizeof(double2) + sizeof(float2)) * FFT_TABLE_MAX, hipHostMallocDefault);
     }
     if (e == hipSuccess) { step = "hipEventCreate"; e = hipEventCreateWithFlags(&c->na.done, hipEventDisableTiming); }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.gray_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.fft_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.stencil_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.gray_ready, INNER_EVENT);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.fft_done, INNER_EVENT);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.stencil_done, INNER_EVENT);
     if (e == hipSuccess) {
         try {
             c->na.redo.reserve(NA_MAX_CHUNK);
