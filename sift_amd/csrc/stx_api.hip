@@ -158,7 +158,8 @@ hipEvent_t get_event(stx_ctx* c) {
         return e;
     }
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    // timing events: a release at device scope, which keeps the event's own cost out of the durations it brackets
+    if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) return nullptr;
     return e;
 }
 
