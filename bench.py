@@ -94,7 +94,7 @@ def self_launch(args) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="1080p")
     ap.add_argument("--frames", type=int, default=0, help="frames per step (0 = the config's)")
