@@ -12,7 +12,7 @@ step bench 1080p
 timeout -k 10 400 python3 bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err || exit 1
 for c in crops256 4k_multiradius 720p; do
   step bench $c
-  timeout -k 10 300 python3 bench.py --config $c --steps 6 --warmup 2 --cpu-seconds 8 > $OUT/bench_$c.json 2> $OUT/bench_$c.err || exit 1
+  timeout -k 10 300 python3 bench.py --config $c --steps 20 --warmup 2 --cpu-seconds 8 > $OUT/bench_$c.json 2> $OUT/bench_$c.err || exit 1
 done
 step host-fed
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --host-fed > $OUT/bench_hostfed.json 2> $OUT/bench_hostfed.err || exit 1
