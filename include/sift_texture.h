@@ -141,8 +141,9 @@ int stx_analyze_batch_device_noalloc(stx_ctx* ctx, const uint8_t* bgr_dev, int n
 
 /* Asynchronous form of stx_analyze_batch_device (no counterpart in the reference): queues the work
  * on the GPU and returns a ticket; stx_wait(ticket) blocks until out[0..n_frames) is filled.  Up to
- * two submissions may be in flight, so the host part of one clip and the memory-bound gray pass of
- * the next overlap the compute-bound kernels of the previous one.  n_frames must not exceed
+ * two submissions may be in flight, so the host's part of a clip (queueing it, collecting the one
+ * before) runs while the device works, and the device goes from one clip's kernels to the next
+ * without idling.  n_frames must not exceed
  * stx_max_async_frames(ctx, h, w); bgr_dev, params and out must stay valid until stx_wait returns.
  * The synchronous entry points refuse to run while a ticket is outstanding. */
 int stx_submit_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w,
