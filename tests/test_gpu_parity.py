@@ -240,6 +240,27 @@ def test_gray_inside_stencil_pass_and_separate_gray_pass(ctx, coracle, monkeypat
         sep.close()
 
 
+def test_per_kernel_timing_by_family(ctx):
+    """stx_set_timing: everything, a chosen set of kernel families, nothing."""
+    f = [synth_frame("natural", SEED, 50, i, 96, 128) for i in range(3)]
+    ctx.get_timing(reset=True)
+    ctx.set_timing(True)
+    ctx.analyze_frames(f)
+    ctx.set_timing(False)
+    t = ctx.get_timing(reset=True)["kernels"]
+    assert t["stencil"]["launches"] == 1 and t["fft_rows"]["launches"] == 1 and t["fft_cols"]["launches"] == 1
+    assert t["hysteresis"]["launches"] >= 1 and t["stencil"]["ms"] > 0
+    assert t["gray"]["launches"] == 0  # a width that is a multiple of four: the stencil pass converts the frames
+    ctx.set_timing(True, kinds=("stencil", "fft_cols"))
+    ctx.analyze_frames(f)
+    ctx.set_timing(False)
+    t = ctx.get_timing(reset=True)
+    assert t["frames"] == 3
+    assert {k for k, v in t["kernels"].items() if v["launches"]} == {"stencil", "fft_cols"}
+    ctx.analyze_frames(f)
+    assert all(v["launches"] == 0 for v in ctx.get_timing()["kernels"].values())
+
+
 def test_odd_fft_sizes(ctx, coracle):
     # prime and mixed sizes exercise the generic butterfly: 17x23, 7*11=77, 2*3*5*7=210, 13
     for (h, w) in [(17, 23), (77, 13), (210, 66), (49, 121), (26, 34)]:
