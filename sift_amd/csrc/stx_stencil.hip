@@ -456,12 +456,9 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     pend |= und >> i;
                     // histogram (and codes): a pixel's half of the bit word is the byte offset of its entry in the
                     // table of one-hot 6-bit counters; undecided pixels add nothing here, the second stage adds them
-                    const uint32_t g = bits | (und >> UNDECIDED_SHIFT);
-                    uint32_t il = g & 0xFFFFu, ih = g >> 16;
-                    if (BORDER) {
-                        il = (y < H && x < W) ? il : (uint32_t)(LUT_INVALID * sizeof(uint2));
-                        ih = (y < H && x + 1 < W) ? ih : (uint32_t)(LUT_INVALID * sizeof(uint2));
-                    }
+                    // (pixels outside the image get bit 11 as well: ~vmy has it, and more, exactly in their halves)
+                    const uint32_t g = bits | (und >> UNDECIDED_SHIFT) | (BORDER ? (~vmy & (HH >> UNDECIDED_SHIFT)) : 0u);
+                    const uint32_t il = g & 0xFFFFu, ih = g >> 16;
                     const uint2 el = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + il);
                     const uint2 eh = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(lut) + ih);
                     hist_a += el.x + eh.x;
