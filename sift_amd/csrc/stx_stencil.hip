@@ -103,6 +103,7 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
     return word(__builtin_elementwise_sub_sat(asU(a), asU(b)));
 }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return word(__builtin_elementwise_min(asU(a), asU(b))); }
+__device__ __forceinline__ uint32_t pk_min_i(uint32_t a, uint32_t b) { return word(__builtin_elementwise_min(asS(a), asS(b))); }
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 // v_bfi_b32 with a constant mask held in a scalar register, as written (the compiler prefers a shift, an and with a
 // literal and a share of a three-way or: two and a third instructions for one)
@@ -136,10 +137,25 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ unsigned long long wave_sum_u64s(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Sums of nine words over the wave, valid in lane 63: shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15
+// of a row into the next row, then lane 31 into the upper half (a lane without a source adds zero, a row that is
+// masked out keeps its value).  Written out as one block of v_add_u32_dpp: the compiler makes a move and an add of
+// each step, and inside the block consecutive uses of a register are nine instructions apart, which covers the wait
+// a data-parallel read needs after a write of the same register (the s_nop covers whatever wrote them last).
+__device__ __forceinline__ void wave_total9(uint32_t (&w)[9]) {
+#define STX_DPP_STEP(ctrl)                                                                                          \
+    "v_add_u32_dpp %0, %0, %0 " ctrl "\n v_add_u32_dpp %1, %1, %1 " ctrl "\n v_add_u32_dpp %2, %2, %2 " ctrl "\n"    \
+    "v_add_u32_dpp %3, %3, %3 " ctrl "\n v_add_u32_dpp %4, %4, %4 " ctrl "\n v_add_u32_dpp %5, %5, %5 " ctrl "\n"    \
+    "v_add_u32_dpp %6, %6, %6 " ctrl "\n v_add_u32_dpp %7, %7, %7 " ctrl "\n v_add_u32_dpp %8, %8, %8 " ctrl "\n"
+    asm("s_nop 1\n"
+        STX_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        STX_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        STX_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        STX_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        STX_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        STX_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]));
+#undef STX_DPP_STEP
 }
 
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -450,8 +466,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                     bits = bfi_lit<0x00100010u>(a4 >> 11, bits);
                     bits = bfi_lit<0x00080008u>(a6 >> 12, bits);
                     // undecided: 0x8000 <= f < 0x8005, i.e. subtracting 5 clears bit 15 (f is at least 0x82)
-                    uint32_t und = (f1 ^ (f1 - TIE_BAND)) | (f3 ^ (f3 - TIE_BAND)) | (f5 ^ (f5 - TIE_BAND)) |
-                                   (f7 ^ (f7 - TIE_BAND));
+                    // (read as signed halves the band is the bottom of the range, so the smallest of the four is in
+                    // it whenever any of them is: three packed minima and one test instead of four tests)
+                    const uint32_t fmin = pk_min_i(pk_min_i(f1, f3), pk_min_i(f5, f7));
+                    uint32_t und = fmin ^ (fmin - TIE_BAND);
                     und &= BORDER ? (vmy & HH) : HH;
                     pend |= und >> i;
                     // histogram (and codes): a pixel's half of the bit word is the byte offset of its entry in the
@@ -656,38 +674,35 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         }
     }
 
-    // ---- wave reduction: 10 histogram bins as 16-bit fields (a strip holds 4096 pixels), four sums
-    unsigned long long w0 = 0, w1 = 0, w2 = 0;
+    // ---- wave reduction.  Nine 32-bit words per lane: the ten histogram bins as 16-bit fields (a strip holds 4096
+    // pixels, a lane 64 of them), the sum of squares (at most 64 * 255^2 per lane), three plain sums (at most 64 * 255 per
+    // lane).  Each word is summed over the wave by six adds whose second operand comes from another lane inside the
+    // instruction; the total arrives in lane 63.
     {
-        auto bin = [&](int b) -> unsigned long long {
-            const int sh = 6 * (b % 5);
-            return b < 5 ? ((hist_a >> sh) & 63u) + ((hist_a0 >> sh) & 63u) : ((hist_b >> sh) & 63u) + ((hist_b0 >> sh) & 63u);
+        auto bin2 = [&](uint32_t h, uint32_t h0, int f) -> uint32_t {  // fields f and f+1 of a counter word, 16 bits apart
+            const uint32_t lo = ((h >> (6 * f)) & 63u) + ((h0 >> (6 * f)) & 63u);
+            const uint32_t hi = ((h >> (6 * f + 6)) & 63u) + ((h0 >> (6 * f + 6)) & 63u);
+            return lo | (hi << 16);
         };
+        uint32_t w[9];
+        w[0] = bin2(hist_a, hist_a0, 0);                                                    // bins 0, 1
+        w[1] = bin2(hist_a, hist_a0, 2);                                                    // bins 2, 3
+        w[2] = (((hist_a >> 24) & 63u) + ((hist_a0 >> 24) & 63u)) | ((((hist_b) & 63u) + ((hist_b0) & 63u)) << 16);  // 4, 5
+        w[3] = bin2(hist_b, hist_b0, 1);                                                    // bins 6, 7
+        w[4] = bin2(hist_b, hist_b0, 3);                                                    // bins 8, 9
+        w[5] = hp_s; w[6] = hp_q; w[7] = ad_s; w[8] = gr_s;
+        wave_total9(w);
+        if (lane == 63) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            w0 |= bin(b) << (16 * b);
-            w1 |= bin(b + 4) << (16 * b);
+            for (int b = 0; b < 5; ++b) {
+                red[2 * b] = w[b] & 0xFFFFu;
+                red[2 * b + 1] = w[b] >> 16;
+            }
+            red[10] = w[5];
+            red[11] = w[6];
+            red[12] = w[7];
+            red[13] = w[8];
         }
-        w2 = bin(8) | (bin(9) << 16) | ((unsigned long long)hp_q << 32);
-    }
-    // high-pass sum, residual sum, gray sum: at most 64*255 per lane, 21-bit fields hold the wave total
-    unsigned long long w3 = (unsigned long long)hp_s | ((unsigned long long)ad_s << 21) | ((unsigned long long)gr_s << 42);
-    w0 = wave_sum_u64s(w0);
-    w1 = wave_sum_u64s(w1);
-    w2 = wave_sum_u64s(w2);
-    w3 = wave_sum_u64s(w3);
-    if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            red[b] = (uint32_t)((w0 >> (16 * b)) & 0xFFFFull);
-            red[b + 4] = (uint32_t)((w1 >> (16 * b)) & 0xFFFFull);
-        }
-        red[8] = (uint32_t)(w2 & 0xFFFFull);
-        red[9] = (uint32_t)((w2 >> 16) & 0xFFFFull);
-        red[10] = (uint32_t)(w3 & 0x1FFFFFull);
-        red[11] = (uint32_t)(w2 >> 32);
-        red[12] = (uint32_t)((w3 >> 21) & 0x1FFFFFull);
-        red[13] = (uint32_t)(w3 >> 42);
     }
 }
 
