@@ -158,6 +158,20 @@ __device__ __forceinline__ void wave_total9(uint32_t (&w)[9]) {
 #undef STX_DPP_STEP
 }
 
+// Inclusive prefix sum over the wave (lane 63 ends up with the total), the same six steps on one word; the s_nop
+// between two steps is the wait a data-parallel read needs after a write of the register it reads.
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    asm("s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 0\n"
+        : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Lanes of one wave exchange data through LDS without a barrier instruction (a wave's LDS operations
@@ -526,9 +540,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 // ---- undecided pixels of this block.  Normally few: their flags wait in LDS for the end of the strip.
                 // Flat regions flag (nearly) every pixel: then the lanes are evenly loaded as they are and each
                 // re-evaluates its own pixels here.
-                uint32_t tot = __popc(pend);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(__popc(pend)), 63);
                 if (tot > DENSE_MIN) {
                     if (!BORDER) {
                         // Flat neighbourhoods first: where the four columns x-1 .. x+2 hold one value over three
@@ -621,23 +633,20 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             // inclusive prefix sum over the wave with data-parallel-primitive adds (no trip through the LDS
             // crossbar): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of a row into the
             // next row, then lane 31 into the upper half
-            uint32_t inc = cnt;
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);  // row_bcast:15
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31
+            const uint32_t inc = wave_scan_u32(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             uint32_t qpos = inc - cnt;
-            // item: (owner lane << 6) | (row of the strip << 1) | pixel, from the position of a flag
+            // item: (owner lane << 6) | (row of the strip << 1) | pixel, from the position of a flag.  Two blocks'
+            // flags share a word (the second block's byte pair moves below the first's: row r of the sixteen at bit
+            // 15-r and 31-r), so the wave runs two loops of the worst lane's count instead of four.
+            static_assert(WAVE_ROWS / BLOCK_ROWS == 4 && BLOCK_ROWS == 8, "flag words are merged in pairs of blocks");
 #pragma unroll
-            for (int b = 0; b < WAVE_ROWS / BLOCK_ROWS; ++b) {
-                uint32_t flags = pq[b];
+            for (int b = 0; b < 2; ++b) {
+                uint32_t flags = pq[2 * b] | (pq[2 * b + 1] >> 8);
                 while (flags != 0) {
                     const uint32_t p = (uint32_t)__ffs(flags) - 1u;
                     flags &= flags - 1;
-                    wq[qpos++] = (uint16_t)(((uint32_t)lane << 6) | ((uint32_t)(b * BLOCK_ROWS + 15 - (int)(p & 15u)) << 1) | (p >> 4));
+                    wq[qpos++] = (uint16_t)(((uint32_t)lane << 6) | ((uint32_t)(b * 16 + 15 - (int)(p & 15u)) << 1) | (p >> 4));
                 }
             }
             wave_sync();
