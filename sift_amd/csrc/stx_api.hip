@@ -23,6 +23,11 @@ constexpr int HYST_FIRST_PASSES = 8;  // grid-wide hysteresis passes queued with
 // barriers instead of launches (up to 63 rounds per launch) -- measured on 150 ordinary 1080p frames the five
 // last grid passes take 34 us and one such launch 44 us, so it is the continuation, not the default.
 constexpr int HYST_GRID_PASSES = HYST_FIRST_PASSES;
+// Raw-threshold chunks (see nms_sparse_kernel): the flood of the raw maps keeps its own pass flags behind the
+// ordinary ones: eight grid-wide passes, two per-frame finishing launches, and in the last word the size of the
+// flooded set.
+constexpr int RAW_GRID_PASSES = 6, RAW_FINISH = 2, RAW_WORDS = 16, RAW_REACHED = 15;
+constexpr int RAW_SECOND_GRID = 4, RAW_SECOND_PASSES = 6;  // the flood after the suppression: passes queued with the chunk
 constexpr int HYST_GROUP = 1;         // further launches per host check when the first batch was not enough
 
 struct DevBuf {
@@ -67,7 +72,7 @@ struct Prepared {
 // One in-flight chunk: its own intermediates and result buffers, so the host can queue chunk
 // i+1 while the device still works on chunk i.
 struct Slot {
-    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, qpart, xpart, acc, changed, staging;
+    DevBuf gray, strong, cand, spec, part, tiles, tflag, spart, lpart, qpart, xpart, acc, changed, staging, nmslist, nmscount, cand2;
     FrameAcc* acc_host = nullptr;  // pinned
     size_t acc_host_cap = 0;
     unsigned int* changed_host = nullptr;  // pinned, one word
@@ -77,6 +82,10 @@ struct Slot {
     stx_metrics* async_out = nullptr;
     Prepared async_pr;
     int passes = 0;  // hysteresis passes queued so far
+    bool raw = false;  // the stencil pass left raw threshold maps: flood, suppression on the flooded set, flood again
+    const uint8_t* src_bgr = nullptr;  // the chunk's frames (a raw chunk whose first flood does not settle is queued again)
+    int64_t src_row_stride = 0, src_frame_stride = 0;
+    uint8_t* src_codes = nullptr;
     int F = 0;
     std::vector<TimedSpan> spans;
     std::vector<uint8_t> pack;  // host rows of strided frames, packed for one linear copy
@@ -113,10 +122,17 @@ struct stx_ctx {
     // the stencil pass converts BGR itself where it can; SIFT_TEXTURE_SEPARATE_GRAY=1 in the environment keeps the
     // separate gray pass for every call (measurements, and tests that run both paths on one input)
     bool fuse_gray = true;
+    // Canny's non-maximum suppression: 0 = in the stencil pass on every pixel, 1 = after a flood of the raw threshold
+    // maps on the flooded set only, 2 = the second while the flooded set stays small (SIFT_TEXTURE_CANNY=dense|sparse|auto)
+    int canny_mode = 2;
+    bool raw_next = true;   // auto: what the next chunk does
+    int dense_run = 0;      // auto: dense chunks since the last sparse one (one in RAW_PROBE is tried sparse again)
+    uint64_t raw_requeued = 0;
     bool timing = false;
     uint32_t timing_kinds = ~0u;       // bit k: launches of kernel family k are bracketed by events while timing is on
     stx_timing tacc;
     std::vector<hipEvent_t> event_pool;
+    std::vector<TimedSpan> spans_kept;
 };
 
 namespace {
@@ -407,7 +423,10 @@ hipError_t upload_frame(uint8_t* dst, int64_t dpitch, const uint8_t* src, int64_
 
 struct ChunkOpts {
     uint8_t* codes = nullptr;  // device, optional [F][H][W]
+    bool force_dense = false;
 };
+constexpr int RAW_PROBE = 32;
+constexpr double RAW_MAX_DENSITY = 0.02;  // flooded pixels per pixel above which the suppression goes back into the stencil pass
 
 
 int prepare(stx_ctx* c, int h, int w, const stx_params* params, Prepared* pr, bool own_twiddles = true) {
@@ -445,13 +464,16 @@ void sync_all(stx_ctx* c) {
 int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g, hipStream_t st = nullptr) {
     if (sl.passes + n > HYST_MAX_PASSES) return fail(c, STX_ERR_UNSUPPORTED, "Canny hysteresis did not converge");
     if (!st) st = c->stream;
+    // (a raw chunk's ordinary passes run on the map the suppression filled)
+    const unsigned long long* cand = (const unsigned long long*)(sl.raw ? sl.cand2.p : sl.cand.p);
     Span sp(c, &sl.spans, STX_K_HYST, n, st);
     for (int i = 0; i < n; ++i, ++sl.passes) {
-        if (sl.passes < HYST_GRID_PASSES)
-            launch_hyst_pass(st, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
+        // (after the suppression on a flooded set few tiles are left to grow: two grid-wide passes, then per-frame ones)
+        if (sl.passes < (sl.raw ? RAW_SECOND_GRID : HYST_GRID_PASSES))
+            launch_hyst_pass(st, (unsigned long long*)sl.strong.p, cand, sl.F, g,
                              (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
         else
-            launch_hyst_finish(st, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, sl.F, g,
+            launch_hyst_finish(st, (unsigned long long*)sl.strong.p, cand, sl.F, g,
                                (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
     }
     sp.end();
@@ -469,6 +491,9 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr, hipStream_t s = null
     }
     HIPCHK(c, hipMemcpyAsync(sl.changed_host, (unsigned int*)sl.changed.p + (sl.passes - 1), sizeof(unsigned int),
                              hipMemcpyDeviceToHost, s));
+    if (sl.raw)  // "the first flood was still growing" and the size of the flooded set, behind the word above
+        HIPCHK(c, hipMemcpyAsync(sl.changed_host + 1, (unsigned int*)sl.changed.p + HYST_MAX_PASSES + RAW_GRID_PASSES + RAW_FINISH - 1,
+                                 (size_t)(RAW_WORDS - (RAW_GRID_PASSES + RAW_FINISH - 1)) * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(sl.acc_host, sl.acc.p, (size_t)sl.F * sizeof(FrameAcc), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(sl.done, s));
     return STX_OK;
@@ -476,8 +501,8 @@ int queue_results(stx_ctx* c, Slot& sl, const Prepared& pr, hipStream_t s = null
 
 // Bytes of every device buffer a chunk of F frames needs, in the order of ChunkBuf.
 enum ChunkBuf { CB_GRAY, CB_STRONG, CB_CAND, CB_SPEC, CB_PART, CB_TILES, CB_TFLAG, CB_SPART, CB_ACC, CB_CHANGED, CB_LPART,
-                CB_QPART, CB_XPART, CB_COUNT };
-void chunk_sizes(const Prepared& pr, int F, size_t (&n)[CB_COUNT]) {
+                CB_QPART, CB_XPART, CB_NMSLIST, CB_NMSCOUNT, CB_CAND2, CB_COUNT };
+void chunk_sizes(const Prepared& pr, int F, size_t (&n)[CB_COUNT], bool raw = false) {
     const Geom& g = pr.g;
     const bool lbp81 = (pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0);
     n[CB_GRAY] = (size_t)F * g.grows * g.gpitch;
@@ -488,14 +513,17 @@ void chunk_sizes(const Prepared& pr, int F, size_t (&n)[CB_COUNT]) {
     n[CB_TFLAG] = (size_t)2 * F * g.bm_tiles * g.bm_words;
     n[CB_SPART] = (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t);
     n[CB_ACC] = (size_t)F * sizeof(FrameAcc);
-    n[CB_CHANGED] = (size_t)HYST_MAX_PASSES * sizeof(unsigned int);
+    n[CB_CHANGED] = (size_t)(HYST_MAX_PASSES + RAW_WORDS) * sizeof(unsigned int);
     n[CB_LPART] = (!lbp81 || pr.ext) ? lbp_generic_part_bytes(g, F) : 0;
     n[CB_QPART] = pr.p.quality_stats ? quality_part_bytes(g, F) : 0;
     n[CB_XPART] = pr.ext ? extended_part_bytes(g, F) : 0;
+    n[CB_NMSLIST] = raw ? (size_t)F * nms_list_cap(g) * sizeof(uint32_t) : 0;
+    n[CB_NMSCOUNT] = raw ? (size_t)F * sizeof(unsigned int) : 0;
+    n[CB_CAND2] = raw ? n[CB_CAND] : 0;
 }
 DevBuf* chunk_buf(Slot& sl, int i) {
     DevBuf* b[CB_COUNT] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.acc,
-                           &sl.changed, &sl.lpart, &sl.qpart, &sl.xpart};
+                           &sl.changed, &sl.lpart, &sl.qpart, &sl.xpart, &sl.nmslist, &sl.nmscount, &sl.cand2};
     return b[i];
 }
 
@@ -509,8 +537,17 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     const stx_params& p = pr.p;
     const FftLayout& lay = pr.lay;
     int rc;
+    sl.src_bgr = bgr_dev; sl.src_row_stride = row_stride; sl.src_frame_stride = frame_stride; sl.src_codes = opts.codes;
+    {
+        const bool eligible = p.lbp_points == 8 && p.lbp_radius == 1.0 && !opts.codes && !opts.force_dense && !sl.gray.fixed;
+        sl.raw = eligible && (c->canny_mode == 1 || (c->canny_mode == 2 && c->raw_next));
+        if (eligible && c->canny_mode == 2 && !sl.raw && ++c->dense_run >= RAW_PROBE) {
+            c->raw_next = true;
+            c->dense_run = 0;
+        }
+    }
     size_t need[CB_COUNT];
-    chunk_sizes(pr, F, need);
+    chunk_sizes(pr, F, need, sl.raw);
     for (int i = 0; i < CB_COUNT; ++i)
         if (need[i] && (rc = ensure(c, *chunk_buf(sl, i), need[i])) != STX_OK) return rc;
     if ((size_t)F > sl.acc_host_cap) {
@@ -559,6 +596,11 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     }
     HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), sclr));
     HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), sclr));
+    if (sl.raw) {
+        HIPCHK(c, hipMemsetAsync((unsigned int*)sl.changed.p + HYST_MAX_PASSES, 0, (size_t)RAW_WORDS * sizeof(unsigned int), sclr));
+        HIPCHK(c, hipMemsetAsync(sl.nmscount.p, 0, (size_t)F * sizeof(unsigned int), sclr));
+        HIPCHK(c, hipMemsetAsync(sl.cand2.p, 0, need[CB_CAND2], sclr));
+    }
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
     if (lbp81 && (rc = ensure_tie_tables(c, pr.off)) != STX_OK) return rc;
     HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, sclr));
@@ -570,7 +612,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         Span sp(c, &sl.spans, STX_K_STENCIL, 1, s);
         launch_stencil(s, (uint8_t*)sl.gray.p, fused_gray ? &bsrc : nullptr, F, g, lbp81, pr.off, p.canny_low, p.canny_high, (uint32_t*)sl.spart.p,
                        (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand.p, lbp81 ? opts.codes : nullptr,
-                       (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words);
+                       (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, sl.raw);
         sp.end();
     }
     HIPCHK(c, hipEventRecord(sl.stencil_done, s));
@@ -606,11 +648,27 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // back to back with no event between them; the hysteresis passes, which leave the device mostly idle, run on the
     // second stream beside the row pass, and so does the collection of the results, beside the next chunk's stencil
     // pass.
-    if (fused_flow) {
-        HIPCHK(c, hipStreamWaitEvent(side, sl.stencil_done, 0));
-        if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g, side)) != STX_OK) return rc;
-    } else {
-        if ((rc = hyst_passes(c, sl, HYST_FIRST_PASSES, g)) != STX_OK) return rc;
+    {
+        hipStream_t hs = fused_flow ? side : s;
+        if (fused_flow) HIPCHK(c, hipStreamWaitEvent(side, sl.stencil_done, 0));
+        if (sl.raw) {
+            // flood of the raw maps (its own pass flags), suppression on what it reached; the ordinary passes then
+            // start from pass 0 on the suppressed maps
+            unsigned int* ch1 = (unsigned int*)sl.changed.p + HYST_MAX_PASSES;
+            Span sp(c, &sl.spans, STX_K_HYST, RAW_GRID_PASSES + RAW_FINISH + 2, hs);
+            for (int k = 0; k < RAW_GRID_PASSES; ++k)
+                launch_hyst_pass(hs, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, F, g, ch1, k,
+                                 (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
+            for (int k = RAW_GRID_PASSES; k < RAW_GRID_PASSES + RAW_FINISH; ++k)
+                launch_hyst_finish(hs, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, F, g, ch1, k,
+                                   (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
+            launch_nms_sparse(hs, (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand2.p, (const uint8_t*)sl.gray.p, F, g,
+                              p.canny_low, p.canny_high, (const uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p, (uint32_t*)sl.nmslist.p,
+                              (unsigned int*)sl.nmscount.p,
+                              ch1 + RAW_GRID_PASSES + RAW_FINISH - 1, ch1 + RAW_REACHED);
+            sp.end();
+        }
+        if ((rc = hyst_passes(c, sl, sl.raw ? RAW_SECOND_PASSES : HYST_FIRST_PASSES, g, hs)) != STX_OK) return rc;
     }
     {
         hipStream_t sf = fused_gray ? s : side;
@@ -736,6 +794,28 @@ hipError_t wait_event(hipEvent_t ev) {
 
 int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx_extended* ext = nullptr) {
     HIPCHK(c, wait_event(sl.done));
+    if (sl.raw) {
+        if (sl.changed_host[1] != 0) {
+            // rare: the flood of the raw maps was still growing when the suppression ran on it (contours hundreds of
+            // tiles long): the chunk goes through again with the suppression in the stencil pass
+            ChunkOpts o;
+            o.codes = sl.src_codes;
+            o.force_dense = true;
+            ++c->raw_requeued;
+            sl.spans.swap(c->spans_kept);  // the first attempt's timing spans stay counted
+            const int rc = enqueue_chunk(c, sl, sl.src_bgr, sl.src_row_stride, sl.src_frame_stride, sl.F, pr, o);
+            if (rc != STX_OK) return rc;
+            sl.spans.insert(sl.spans.end(), c->spans_kept.begin(), c->spans_kept.end());
+            c->spans_kept.clear();
+            HIPCHK(c, wait_event(sl.done));
+        } else if (c->canny_mode == 2) {
+            const double px = (double)sl.F * (double)pr.g.H * (double)pr.g.W;
+            if ((double)sl.changed_host[1 + RAW_REACHED - (RAW_GRID_PASSES + RAW_FINISH - 1)] > RAW_MAX_DENSITY * px) {
+                c->raw_next = false;
+                c->dense_run = 0;
+            }
+        }
+    }
     while (*sl.changed_host != 0) {
         // rare: long contours still growing after the first batch of passes
         int rc;
@@ -843,6 +923,9 @@ int stx_create(int device_id, stx_ctx** out) {
     {
         const char* sep = getenv("SIFT_TEXTURE_SEPARATE_GRAY");
         c->fuse_gray = !(sep && sep[0] && sep[0] != '0');
+        const char* cm = getenv("SIFT_TEXTURE_CANNY");
+        if (cm && !strcmp(cm, "dense")) c->canny_mode = 0;
+        else if (cm && !strcmp(cm, "sparse")) c->canny_mode = 1;
     }
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
@@ -912,7 +995,7 @@ int stx_destroy(stx_ctx* c) {
     (void)hipSetDevice(c->device);
     sync_all(c);
     for (Slot& sl : c->slot) {
-        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.qpart, &sl.xpart, &sl.acc, &sl.changed, &sl.staging};
+        DevBuf* bufs[] = {&sl.gray, &sl.strong, &sl.cand, &sl.spec, &sl.part, &sl.tiles, &sl.tflag, &sl.spart, &sl.lpart, &sl.qpart, &sl.xpart, &sl.acc, &sl.changed, &sl.staging, &sl.nmslist, &sl.nmscount, &sl.cand2};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.acc_host) (void)hipHostFree(sl.acc_host);

@@ -13,6 +13,8 @@
 // iterates to its local fix-point, then the host launches further passes until a pass
 // changes nothing anywhere (stale reads of a neighbouring tile's words are harmless: the
 // map only ever grows, and the last pass re-checks every tile against final neighbours).
+#include <cstdlib>
+
 #include "stx_internal.h"
 
 namespace stx {
@@ -272,6 +274,195 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
     }
 }
 
+// Non-maximum suppression after the fact.  When the stencil pass leaves the RAW double threshold in the maps
+// (magnitude above low / above high, no suppression), a flood of those maps reaches a superset of the pixels
+// cv2.Canny (passive_checker.py:116) can mark: an edge pixel is a suppressed candidate connected to a suppressed
+// strong pixel through suppressed candidates, all of which are raw candidates connected to a raw strong pixel.  On
+// camera-like frames that superset is a fraction of a percent of the image (a seventh of the pixels exceed the low
+// threshold, a thousandth the high one, and 8-connected clusters at that density stay small), so the suppression --
+// three Sobel magnitudes, the direction tests and three comparisons per pixel -- runs here on those pixels only,
+// recomputed from the gray plane, instead of on every pixel in the stencil pass.  Afterwards `cand` holds the
+// suppressed candidates inside the flooded set, `strong` the suppressed strong pixels, and the ordinary hysteresis
+// passes run on them from pass 0.
+//
+// Two kernels.  nms_collect_kernel looks at the per-tile counts the flood left (64 tiles at a time, one per lane) and,
+// for every tile that holds flooded pixels, a wave (lane = pixel column, word = 64 rows) appends them to the frame's
+// list -- one atomic per tile reserves the room -- and clears the tile's words of `strong` and the tiles' flags.  nms_apply_kernel takes one list entry per
+// thread, so the work is spread evenly however the pixels cluster; a pixel that passes sets its bit in `cand2` (a map
+// the caller zeroed; and in `strong`, and sets its tile's flag) with an atomic or.  A frame whose list would overflow (the
+// flooded set is larger than 4 % of the frame) raises *unsettled and the caller runs the chunk the ordinary way.
+constexpr int NMS_WAVES = 4;
+// L1 Sobel magnitude of the replicate-bordered gray image at (y, x); 0 outside the image
+__device__ __forceinline__ int nms_mag(const uint8_t* gp, int gpitch, int H, int W, int y, int x, int* gxo, int* gyo) {
+    if (y < 0 || y >= H || x < 0 || x >= W) return 0;
+    const int ym = y > 0 ? y - 1 : 0, yp = y + 1 < H ? y + 1 : H - 1;
+    const int xm = x > 0 ? x - 1 : 0, xp = x + 1 < W ? x + 1 : W - 1;
+    const uint8_t* r0 = gp + (int64_t)(ym + GRAY_YOFF) * gpitch + GRAY_XOFF;
+    const uint8_t* r1 = gp + (int64_t)(y + GRAY_YOFF) * gpitch + GRAY_XOFF;
+    const uint8_t* r2 = gp + (int64_t)(yp + GRAY_YOFF) * gpitch + GRAY_XOFF;
+    const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], g = r2[xm], h = r2[x], i = r2[xp];
+    const int gx = (c - a) + 2 * (f - d) + (i - g);
+    const int gy = (g - a) + 2 * (h - b) + (i - c);
+    if (gxo) { *gxo = gx; *gyo = gy; }
+    return abs(gx) + abs(gy);
+}
+// the same from three rows of a patch held in registers: bytes 0..2 of r0, r1, r2 are the three columns
+__device__ __forceinline__ int patch_mag(uint32_t r0, uint32_t r1, uint32_t r2, int* gxo, int* gyo) {
+    const int a = r0 & 255u, b = (r0 >> 8) & 255u, c = (r0 >> 16) & 255u, d = r1 & 255u, f = (r1 >> 16) & 255u;
+    const int g = r2 & 255u, h = (r2 >> 8) & 255u, i = (r2 >> 16) & 255u;
+    const int gx = (c - a) + 2 * (f - d) + (i - g);
+    const int gy = (g - a) + 2 * (h - b) + (i - c);
+    if (gxo) { *gxo = gx; *gyo = gy; }
+    return abs(gx) + abs(gy);
+}
+__global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned long long* __restrict__ strong, int nlines,
+                                                                     int nwords, int ntiles, int total_tiles,
+                                                                     const uint32_t* __restrict__ tile_count,
+                                                                     uint8_t* __restrict__ sflag,
+                                                                     uint32_t* __restrict__ list, int list_cap,
+                                                                     unsigned int* __restrict__ count,
+                                                                     unsigned int* __restrict__ unsettled,
+                                                                     unsigned int* __restrict__ reached_total) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * NMS_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * NMS_WAVES;
+    const int tpf = ntiles * nwords;
+    unsigned int reached = 0;
+    // lane l of wave w looks at tile (j0 + l) * nwaves + w: the tiles of a busy region are spread over many waves
+    for (int j0 = 0; j0 * nwaves + wave < total_tiles; j0 += 64) {
+        const int mine = (j0 + lane) * nwaves + wave;
+        if (mine < total_tiles) sflag[mine] = 0;
+        unsigned long long todo = __ballot(mine < total_tiles && tile_count[mine] != 0);
+        while (todo) {
+            const int tile_id = (j0 + __ffsll((long long)todo) - 1) * nwaves + wave;
+            todo &= todo - 1;
+            const int frame = tile_id / tpf;
+            const int rem = tile_id - frame * tpf;
+            const int tl = rem / nwords, wx = rem - tl * nwords;
+            const int ln = tl * 64 + lane;
+            const bool lin = ln < nlines;
+            const int64_t idx = ((int64_t)frame * nwords + wx) * nlines + ln;
+            const unsigned long long R = lin ? strong[idx] : 0ull;
+            const uint32_t cnt = (uint32_t)__popcll(R);
+            if (!__any(cnt != 0)) continue;
+            if (R != 0) strong[idx] = 0ull;
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            const uint32_t total = __shfl(inc, 63, 64);
+            uint32_t base = 0;
+            if (lane == 0) {
+                base = atomicAdd(&count[frame], total);
+                reached += total;
+            }
+            base = __shfl(base, 0, 64);
+            if (base + total > (uint32_t)list_cap) {  // wave-uniform
+                if (lane == 0) *unsettled = 1u;
+                continue;
+            }
+            uint32_t* dst = list + (int64_t)frame * list_cap + base + (inc - cnt);
+            for (unsigned long long w = R; w != 0; w &= w - 1)
+                *dst++ = ((uint32_t)(wx * 64 + (__ffsll((long long)w) - 1)) << 13) | (uint32_t)ln;
+        }
+    }
+    if (lane == 0 && reached) atomicAdd(reached_total, reached);
+}
+__global__ __launch_bounds__(256) void nms_apply_kernel(unsigned long long* __restrict__ strong,
+                                                        unsigned long long* __restrict__ cand2,
+                                                        const uint8_t* __restrict__ gray, int gpitch, int grows, int H,
+                                                        int nlines, int nwords, int ntiles, int low, int high,
+                                                        uint8_t* __restrict__ sflag, const uint32_t* __restrict__ list,
+                                                        int list_cap, const unsigned int* __restrict__ count, int dbg) {
+    // grid: (blocks per frame, frames); a workgroup reads its frame's count once and walks over the list with the
+    // grid's stride, so a frame with a short list costs the others nothing
+    const int tpf = ntiles * nwords;
+    const int frame = blockIdx.y;
+    const unsigned int n = count[frame];
+    if (n > (unsigned int)list_cap) return;  // (an overflowed frame is redone by the caller)
+    const uint8_t* gp = gray + (int64_t)frame * grows * gpitch;
+    const int W = nlines;
+    const int lane = threadIdx.x & 63;
+    for (unsigned int i0 = blockIdx.x * 256u + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * 256u) {  // wave-uniform
+        const unsigned int i = i0 + lane;
+        const bool live = i < n;
+        const uint32_t item = live ? list[(int64_t)frame * list_cap + i] : list[(int64_t)frame * list_cap + n - 1];
+        const int x = (int)(item & 8191u), y = (int)(item >> 13);
+        int m, na, nb, slack;
+        if (dbg & 2) { m = (int)item; na = 0; nb = 0; slack = 0; } else
+        if (y >= 2 && y + 2 < H && x >= 2 && x + 2 < W) {
+            // the 5x5 patch around the pixel, five rows of two aligned words each: every load is issued before the
+            // first is used, and a row costs one or two cache lines instead of a line per byte
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(gp + (int64_t)(y - 2 + GRAY_YOFF) * gpitch + (x - 2 + GRAY_XOFF));
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a0 & 3u) * 8u;
+            const int wpitch = gpitch >> 2;
+            unsigned long long row[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                row[r] = ((unsigned long long)q[r * wpitch] | ((unsigned long long)q[r * wpitch + 1] << 32)) >> sh;
+            int gx, gy;
+            m = patch_mag((uint32_t)(row[1] >> 8), (uint32_t)(row[2] >> 8), (uint32_t)(row[3] >> 8), &gx, &gy);
+            const int ax = abs(gx), ay = abs(gy);
+            const int q22 = (ax * 13573) >> 15;    // floor(|gx| tan 22.5 deg)
+            const bool nothoriz = ay > q22;         // |gy| > tan 22.5 |gx|
+            const bool vert = ay > 2 * ax + q22;    // |gy| > tan 67.5 |gx|
+            const bool opp = (gx ^ gy) < 0;
+            // first neighbour at (dy, dx), second at (-dy, -dx)
+            int dy, dx;
+            if (!nothoriz) { dy = 0; dx = -1; slack = 1; }
+            else if (vert) { dy = -1; dx = 0; slack = 1; }
+            else if (opp) { dy = -1; dx = 1; slack = 0; }
+            else { dy = -1; dx = -1; slack = 0; }
+            // rows of the first neighbour's 3x3 window are row[1+dy .. 3+dy], of the second row[1-dy .. 3-dy]
+            const unsigned long long a_0 = dy ? row[0] : row[1], a_1 = dy ? row[1] : row[2], a_2 = dy ? row[2] : row[3];
+            const unsigned long long b_0 = dy ? row[2] : row[1], b_1 = dy ? row[3] : row[2], b_2 = dy ? row[4] : row[3];
+            const uint32_t sa = (uint32_t)(1 + dx) * 8u, sb = (uint32_t)(1 - dx) * 8u;
+            na = patch_mag((uint32_t)(a_0 >> sa), (uint32_t)(a_1 >> sa), (uint32_t)(a_2 >> sa), nullptr, nullptr);
+            nb = patch_mag((uint32_t)(b_0 >> sb), (uint32_t)(b_1 >> sb), (uint32_t)(b_2 >> sb), nullptr, nullptr);
+        } else {
+            int gx, gy;
+            m = nms_mag(gp, gpitch, H, W, y, x, &gx, &gy);
+            const int ax = abs(gx), ay = abs(gy);
+            const int q22 = (ax * 13573) >> 15;
+            const bool nothoriz = ay > q22;
+            const bool vert = ay > 2 * ax + q22;
+            const bool opp = (gx ^ gy) < 0;
+            int ya, xa, yb, xb;
+            if (!nothoriz) { ya = y; xa = x - 1; yb = y; xb = x + 1; slack = 1; }
+            else if (vert) { ya = y - 1; xa = x; yb = y + 1; xb = x; slack = 1; }
+            else if (opp) { ya = y - 1; xa = x + 1; yb = y + 1; xb = x - 1; slack = 0; }
+            else { ya = y - 1; xa = x - 1; yb = y + 1; xb = x + 1; slack = 0; }
+            na = nms_mag(gp, gpitch, H, W, ya, xa, nullptr, nullptr);
+            nb = nms_mag(gp, gpitch, H, W, yb, xb, nullptr, nullptr);
+        }
+        // the second neighbour is compared with >= for horizontal / vertical gradients
+        // Entries of one map word (a column's 64 rows) are neighbours in the list: their bits are combined across the
+        // lanes first (a segmented or, six steps), and the last lane of a run issues the one atomic for it.
+        const bool keep = live && m > low && m > na && m > nb - slack;  // the second neighbour is compared with >= for horizontal / vertical gradients
+        const bool keep_s = keep && m > high;
+        const int64_t idx = ((int64_t)frame * nwords + (y >> 6)) * nlines + x;
+        const unsigned long long bit = 1ull << (y & 63);
+        unsigned long long vc = keep ? bit : 0ull, vs = keep_s ? bit : 0ull;
+        const uint32_t key = live ? item >> 19 << 13 | (item & 8191u) : 0xFFFFFFFFu;  // (word row, column)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t k2 = __shfl_up(key, o, 64);
+            const unsigned long long c2 = __shfl_up(vc, o, 64), s2 = __shfl_up(vs, o, 64);
+            if (lane >= o && k2 == key) { vc |= c2; vs |= s2; }
+        }
+        const uint32_t knext = __shfl_down(key, 1, 64);
+        if (live && (lane == 63 || knext != key) && !(dbg & 1)) {
+            if (vc) atomicOr(&cand2[idx], vc);
+            if (vs) {
+                atomicOr(&strong[idx], vs);
+                sflag[(int64_t)frame * tpf + (x >> 6) * nwords + (y >> 6)] = 1;
+            }
+        }
+    }
+}
+
 // Per-frame reduction of everything the other kernels left as partials, in a fixed order
 // (bit-reproducible): stencil tile sums -> LBP histogram / high-pass / residual / gray sums,
 // hysteresis tile counts -> edge count, FFT column partials -> log-magnitude sums.
@@ -360,6 +551,29 @@ void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigne
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     hipLaunchKernelGGL(hyst_finish_kernel, dim3(n_frames), dim3(1024), 0, s, strong, cand, g.W, g.bm_words, g.bm_tiles,
                        changed, pass, tile_count, tflag, half);
+}
+
+int nms_list_cap(const Geom& g) {
+    const int64_t px = (int64_t)g.H * g.W;
+    const int64_t cap = px / 25;  // LIST_FRACTION: 4 % of the frame
+    return (int)(cap < 1024 ? 1024 : cap);
+}
+void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long long* cand2, const uint8_t* gray, int n_frames,
+                       const Geom& g, int low, int high, const uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
+                       unsigned int* count, unsigned int* unsettled, unsigned int* reached_total) {
+    const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
+    const int total = (int)half;
+    const int cap = nms_list_cap(g);
+    int grid = (total + 64 * NMS_WAVES - 1) / (64 * NMS_WAVES);
+    if (grid > HYST_LATER_GRID) grid = HYST_LATER_GRID;
+    hipLaunchKernelGGL(nms_collect_kernel, dim3(grid), dim3(64 * NMS_WAVES), 0, s, strong, g.W, g.bm_words, g.bm_tiles, total,
+                       tile_count, tflag + half, list, cap, count, unsettled, reached_total);
+    // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound (as in the stencil pass)
+    const int lo = low < -1 ? -1 : (low > 4095 ? 4095 : low), hi = high < -1 ? -1 : (high > 4095 ? 4095 : high);
+    const int bpf = (cap + 255) / 256;
+    hipLaunchKernelGGL(nms_apply_kernel, dim3((unsigned)(bpf < 32 ? bpf : 32), (unsigned)n_frames), dim3(256), 0, s, strong, cand2,
+                       gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count,
+                       getenv("SIFT_TEXTURE_NMSDBG") ? atoi(getenv("SIFT_TEXTURE_NMSDBG")) : 0);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

@@ -106,7 +106,8 @@ bool stencil_reads_bgr(const Geom& g, const BgrSource& src);
 // while it loads its tiles and writes the plane, reflected frame included, for the kernels after it.
 void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag);
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag,
+                    bool raw_canny = false);
 // Tables the (P=8,R=1) LBP uses for flat neighbourhoods (built on the host once per context and copied to the
 // device as one blob); TIE_COORDS entries per coordinate table cover every row / column a tile can touch.
 constexpr int TIE_COORDS = STX_MAX_DIM + 256;
@@ -130,6 +131,16 @@ void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned 
 // round limit is reached: then changed[pass] is set and the caller queues it again).
 void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
+// After a flood of RAW threshold maps (`strong` = the flooded set, tile_count = its size per tile as the flood left it):
+// non-maximum suppression of the pixels in the set from the gray plane.  Leaves the suppressed candidates in `cand2`
+// (zeroed by the caller), "tile holds a strong pixel" in the second half of tflag (what hysteresis pass 0 reads), the
+// suppressed strong pixels in `strong`, and adds the size of the set to *reached_total.
+// list: [n_frames][nms_list_cap(g)] entries, count: [n_frames], zeroed by the caller; *unsettled is set when a frame's
+// set does not fit its list (the maps are then unusable and the caller runs the chunk the ordinary way).
+int nms_list_cap(const Geom& g);
+void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long long* cand2, const uint8_t* gray, int n_frames,
+                       const Geom& g, int low, int high, const uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
+                       unsigned int* count, unsigned int* unsettled, unsigned int* reached_total);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
                          const FftPart* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
 void launch_edges_expand(hipStream_t s, const unsigned long long* strong, const Geom& g, uint8_t* edges);

@@ -254,7 +254,9 @@ struct RowD {
     uint32_t d, sm;         // horizontal Sobel difference and smoothing (replicated border, Canny view)
 };
 
-template <bool BORDER, bool DO_LBP, bool CODES>
+// RAW: the Canny bits are the raw double threshold (magnitude above low / above high) without non-maximum
+// suppression; the suppression then runs on the few pixels a flood of these maps reaches (nms_sparse_kernel).
+template <bool BORDER, bool DO_LBP, bool CODES, bool RAW>
 __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile, const uint2* lut,
                                       uint16_t* wq /*[QUEUE_ITEMS] per wave*/, uint32_t* wpend /*[blocks][64] per wave*/,
                                       int frame, int x0, int y0, int lane, int wv, uint32_t* red /*[16] per wave*/) {
@@ -301,8 +303,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // visit rotates the two registers by one lane, so that lane 0 / lane 63 hold the current row's value where the
     // lane shift of the magnitudes leaves its gap.
     int haloL16 = 0, haloR = 0;
-    if (lane < WAVE_ROWS + 2) haloL16 = mag_at(ys - 1 + lane, x0 - 1) << 16;  // high half: the pair (x0-2, x0-1)
-    if (lane > 63 - (WAVE_ROWS + 2)) haloR = mag_at(ys - 1 + 63 - lane, x0 + TILE_W);  // low half of (x0+128, x0+129)
+    if (!RAW && lane < WAVE_ROWS + 2) haloL16 = mag_at(ys - 1 + lane, x0 - 1) << 16;  // high half: the pair (x0-2, x0-1)
+    if (!RAW && lane > 63 - (WAVE_ROWS + 2)) haloR = mag_at(ys - 1 + 63 - lane, x0 + TILE_W);  // low half of (x0+128, x0+129)
 
     // rel: row index relative to ys-2 (0 .. WAVE_ROWS+3); off: LDS byte offset of (that row, column x-2)
     const uint32_t wave_off = (uint32_t)((wv * WAVE_ROWS) * LPITCH + 2 * lane + 2);
@@ -361,18 +363,20 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         o.sxy = gx ^ gy;
         uint32_t m = o.ax + o.ay;  // at most 2040 per half
         if (BORDER) m &= (r >= 0 && r < H) ? vm : 0u;
-        // The rotations first: every lane of a rotation has a source, so no register has to hold a value for lanes
-        // without one, and the shifts after them can then write into the old halo registers, which are dead by then
-        // (the other way round each shift costs a register copy).
-        const int nextL = __builtin_amdgcn_mov_dpp(haloL16, 0x134, 0xf, 0xf, false);  // wave_rol:1, lane i takes lane i+1
-        const int nextR = __builtin_amdgcn_mov_dpp(haloR, 0x13C, 0xf, 0xf, false);    // wave_ror:1, lane i takes lane i-1
-        const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(haloL16, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(haloR, (int)m, 0x130, 0xf, 0xf, false);    // wave_shl:1
-        haloL16 = nextL;
-        haloR = nextR;
         o.M = m;
-        o.ML = __builtin_amdgcn_alignbit(m, mp, 16);
-        o.MR = __builtin_amdgcn_alignbit(mn, m, 16);
+        if (!RAW) {
+            // The rotations first: every lane of a rotation has a source, so no register has to hold a value for
+            // lanes without one, and the shifts after them can then write into the old halo registers, which are dead
+            // by then (the other way round each shift costs a register copy).
+            const int nextL = __builtin_amdgcn_mov_dpp(haloL16, 0x134, 0xf, 0xf, false);  // wave_rol:1, lane i takes lane i+1
+            const int nextR = __builtin_amdgcn_mov_dpp(haloR, 0x13C, 0xf, 0xf, false);    // wave_ror:1, lane i takes lane i-1
+            const uint32_t mp = (uint32_t)__builtin_amdgcn_update_dpp(haloL16, (int)m, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const uint32_t mn = (uint32_t)__builtin_amdgcn_update_dpp(haloR, (int)m, 0x130, 0xf, 0xf, false);    // wave_shl:1
+            haloL16 = nextL;
+            haloR = nextR;
+            o.ML = __builtin_amdgcn_alignbit(m, mp, 16);
+            o.MR = __builtin_amdgcn_alignbit(mn, m, 16);
+        }
     };
 
     // sliding state: rows y-2..y+2 of the binomial row sums, y-1..y+2 of the rest
@@ -507,7 +511,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 {
                     const uint32_t m = mg[1].M;
                     const uint32_t nz = pk_sub(a.low2, m);  // negative where m > low
-                    if (__any((nz & 0x80008000u) != 0)) {
+                    if (RAW) {
+                        if (__any((nz & 0x80008000u) != 0)) {
+                            const uint32_t ks = nz & pk_sub(a.high2, m);
+                            accC |= (nz >> (8 + i)) & (0x00800080u >> i);
+                            accS |= (ks >> (8 + i)) & (0x00800080u >> i);
+                        }
+                    } else if (__any((nz & 0x80008000u) != 0)) {
                         const uint32_t ax = mg[1].ax, ay = mg[1].ay;
                         const uint32_t q22 = pk_shr<7>(pk_mad<53>(ax, pk_shr<8>(pk_mul<5>(ax))));
                         const uint32_t nothoriz = pk_sign_mask(pk_sub(q22, ay));              // |gy| > tan22 |gx|
@@ -816,7 +826,7 @@ __device__ __forceinline__ void load_tile_bgr(const StencilArgs& a, uint32_t* ti
     }
 }
 
-template <bool DO_LBP, bool CODES, bool FROM_BGR>
+template <bool DO_LBP, bool CODES, bool FROM_BGR, bool RAW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL_WAVES, STX_STENCIL_WAVES))) void stencil_kernel(StencilArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[LROWS * LDW];
     __shared__ uint2 lut[LUT_ENTRIES];
@@ -900,9 +910,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_STENCIL
         // interior: the wave's strip and its two-pixel halo lie inside the image
         const bool interior = (x0 >= 2) && (ys >= 2) && (x0 + TILE_W + 2 <= a.W) && (ys + WAVE_ROWS + 2 <= a.H);
         if (interior)
-            march<false, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<false, DO_LBP, CODES, RAW>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
         else
-            march<true, DO_LBP, CODES>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
+            march<true, DO_LBP, CODES, RAW>(a, reinterpret_cast<const uint8_t*>(tile), lut, wq[wv], wpend[wv], frame, x0, y0, lane, wv, red[wv]);
     } else if ((ys >> 6) < a.bm_words) {
         // a strip below the image that shares its 64-row bitmap word with image rows: its half is empty
         const int64_t wbase = ((int64_t)frame * a.bm_words + (ys >> 6)) * a.W;
@@ -964,7 +974,7 @@ bool stencil_reads_bgr(const Geom& g, const BgrSource& src) {
 
 void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_frames, const Geom& g, bool do_lbp81,
                     const LbpOffsets& off, int low, int high, uint32_t* part, unsigned long long* strong,
-                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag) {
+                    unsigned long long* cand, uint8_t* codes_out, const uint8_t* tie_blob, uint8_t* sflag, bool raw_canny) {
     StencilArgs a;
     a.bgr = nullptr;
     a.row_stride = a.frame_stride = 0;
@@ -1006,19 +1016,25 @@ void launch_stencil(hipStream_t s, uint8_t* gray, const BgrSource* src, int n_fr
     a.codes = codes_out;
     if ((int64_t)g.tiles_x * g.tiles_y * n_frames > 0x7FFFFFFF) abort();
     dim3 grid((unsigned)(g.tiles_x * g.tiles_y * n_frames), 1, 1);
+    // the raw double threshold is compiled for the (8,1) kernels without a code plane only
+    if (raw_canny && (!do_lbp81 || codes_out)) abort();
     if (src) {
         if (!do_lbp81)
-            hipLaunchKernelGGL((stencil_kernel<false, false, true>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((stencil_kernel<false, false, true, false>), grid, dim3(256), 0, s, a);
         else if (codes_out)
-            hipLaunchKernelGGL((stencil_kernel<true, true, true>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((stencil_kernel<true, true, true, false>), grid, dim3(256), 0, s, a);
+        else if (raw_canny)
+            hipLaunchKernelGGL((stencil_kernel<true, false, true, true>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((stencil_kernel<true, false, true>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((stencil_kernel<true, false, true, false>), grid, dim3(256), 0, s, a);
     } else if (!do_lbp81)
-        hipLaunchKernelGGL((stencil_kernel<false, false, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((stencil_kernel<false, false, false, false>), grid, dim3(256), 0, s, a);
     else if (codes_out)
-        hipLaunchKernelGGL((stencil_kernel<true, true, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((stencil_kernel<true, true, false, false>), grid, dim3(256), 0, s, a);
+    else if (raw_canny)
+        hipLaunchKernelGGL((stencil_kernel<true, false, false, true>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((stencil_kernel<true, false, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((stencil_kernel<true, false, false, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace stx
