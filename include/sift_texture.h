@@ -227,6 +227,19 @@ int stx_set_concurrency(stx_ctx* ctx, int enabled);
  * that wants one family's durations without slowing the rest of the path names just that one). */
 int stx_set_timing(stx_ctx* ctx, int enabled);
 int stx_get_timing(stx_ctx* ctx, stx_timing* out, int reset);
+/* Where the non-maximum suppression of cv2.Canny (passive_checker.py:116) runs; the edge map is the same either way.
+ * STX_CANNY_DENSE: in the stencil pass, on every pixel.  STX_CANNY_SPARSE: the stencil pass leaves the raw double
+ * threshold, a flood of those maps finds the pixels an edge can reach, the suppression runs on those only (a fraction
+ * of a percent of a camera frame), the ordinary hysteresis follows; a chunk whose flood does not settle in its passes,
+ * or reaches more than 4 % of a frame, goes through again the dense way.  STX_CANNY_AUTO (default): sparse while the
+ * flooded set stays below 2 % of the pixels, dense otherwise, with one chunk in 32 tried sparse again.  Calls that ask
+ * for code planes, LBP radii other than (8,1) and the allocation-free entry point are always dense.  The environment
+ * variable SIFT_TEXTURE_CANNY=dense|sparse|auto sets the mode a new context starts with. */
+#define STX_CANNY_DENSE 0
+#define STX_CANNY_SPARSE 1
+#define STX_CANNY_AUTO 2
+int stx_set_canny_mode(stx_ctx* ctx, int mode);
+
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ EXPORTS = (
     "stx_analyze_batch", "stx_analyze_frames", "stx_analyze_batch_device", "stx_analyze_batch_device_noalloc", "stx_submit_batch_device", "stx_wait",
     "stx_max_async_frames", "stx_score_summary",
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
-    "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing",
+    "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing", "stx_set_canny_mode",
     "stx_get_timing", "stx_preprocess_frames", "stx_preprocess_batch_device",
     "stx_analyze_extended_frames", "stx_analyze_extended_batch_device",
 )
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
     L.stx_set_chunk_frames.argtypes = [C.c_void_p, C.c_int]
     L.stx_set_concurrency.argtypes = [C.c_void_p, C.c_int]
     L.stx_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.stx_set_canny_mode.argtypes = [C.c_void_p, C.c_int]
     L.stx_get_timing.argtypes = [C.c_void_p, C.POINTER(StxTiming), C.c_int]
     L.stx_preprocess_frames.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.c_int, C.c_void_p]

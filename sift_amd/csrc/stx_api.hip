@@ -24,7 +24,7 @@ constexpr int HYST_FIRST_PASSES = 8;  // grid-wide hysteresis passes queued with
 // last grid passes take 34 us and one such launch 44 us, so it is the continuation, not the default.
 constexpr int HYST_GRID_PASSES = HYST_FIRST_PASSES;
 // Raw-threshold chunks (see nms_sparse_kernel): the flood of the raw maps keeps its own pass flags behind the
-// ordinary ones: eight grid-wide passes, two per-frame finishing launches, and in the last word the size of the
+// ordinary ones: four grid-wide passes, two per-frame finishing launches, and in the last word the size of the
 // flooded set.
 constexpr int RAW_GRID_PASSES = 6, RAW_FINISH = 2, RAW_WORDS = 16, RAW_REACHED = 15;
 constexpr int RAW_SECOND_GRID = 4, RAW_SECOND_PASSES = 6;  // the flood after the suppression: passes queued with the chunk
@@ -122,9 +122,8 @@ struct stx_ctx {
     // the stencil pass converts BGR itself where it can; SIFT_TEXTURE_SEPARATE_GRAY=1 in the environment keeps the
     // separate gray pass for every call (measurements, and tests that run both paths on one input)
     bool fuse_gray = true;
-    // Canny's non-maximum suppression: 0 = in the stencil pass on every pixel, 1 = after a flood of the raw threshold
-    // maps on the flooded set only, 2 = the second while the flooded set stays small (SIFT_TEXTURE_CANNY=dense|sparse|auto)
-    int canny_mode = 2;
+    // where Canny's non-maximum suppression runs (stx_set_canny_mode; SIFT_TEXTURE_CANNY=dense|sparse|auto)
+    int canny_mode = STX_CANNY_AUTO;
     bool raw_next = true;   // auto: what the next chunk does
     int dense_run = 0;      // auto: dense chunks since the last sparse one (one in RAW_PROBE is tried sparse again)
     uint64_t raw_requeued = 0;
@@ -540,8 +539,8 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     sl.src_bgr = bgr_dev; sl.src_row_stride = row_stride; sl.src_frame_stride = frame_stride; sl.src_codes = opts.codes;
     {
         const bool eligible = p.lbp_points == 8 && p.lbp_radius == 1.0 && !opts.codes && !opts.force_dense && !sl.gray.fixed;
-        sl.raw = eligible && (c->canny_mode == 1 || (c->canny_mode == 2 && c->raw_next));
-        if (eligible && c->canny_mode == 2 && !sl.raw && ++c->dense_run >= RAW_PROBE) {
+        sl.raw = eligible && (c->canny_mode == STX_CANNY_SPARSE || (c->canny_mode == STX_CANNY_AUTO && c->raw_next));
+        if (eligible && c->canny_mode == STX_CANNY_AUTO && !sl.raw && ++c->dense_run >= RAW_PROBE) {
             c->raw_next = true;
             c->dense_run = 0;
         }
@@ -808,7 +807,7 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx
             sl.spans.insert(sl.spans.end(), c->spans_kept.begin(), c->spans_kept.end());
             c->spans_kept.clear();
             HIPCHK(c, wait_event(sl.done));
-        } else if (c->canny_mode == 2) {
+        } else if (c->canny_mode == STX_CANNY_AUTO) {
             const double px = (double)sl.F * (double)pr.g.H * (double)pr.g.W;
             if ((double)sl.changed_host[1 + RAW_REACHED - (RAW_GRID_PASSES + RAW_FINISH - 1)] > RAW_MAX_DENSITY * px) {
                 c->raw_next = false;
@@ -924,8 +923,8 @@ int stx_create(int device_id, stx_ctx** out) {
         const char* sep = getenv("SIFT_TEXTURE_SEPARATE_GRAY");
         c->fuse_gray = !(sep && sep[0] && sep[0] != '0');
         const char* cm = getenv("SIFT_TEXTURE_CANNY");
-        if (cm && !strcmp(cm, "dense")) c->canny_mode = 0;
-        else if (cm && !strcmp(cm, "sparse")) c->canny_mode = 1;
+        if (cm && !strcmp(cm, "dense")) c->canny_mode = STX_CANNY_DENSE;
+        else if (cm && !strcmp(cm, "sparse")) c->canny_mode = STX_CANNY_SPARSE;
     }
     const char* step = "hipSetDevice";
     e = hipSetDevice(device_id);
@@ -1513,6 +1512,13 @@ int stx_set_chunk_frames(stx_ctx* c, int frames) {
 int stx_set_concurrency(stx_ctx* c, int enabled) {
     if (!c) return STX_ERR_INVALID;
     c->concurrent_fft = enabled != 0;
+    return STX_OK;
+}
+int stx_set_canny_mode(stx_ctx* c, int mode) {
+    if (!c || mode < STX_CANNY_DENSE || mode > STX_CANNY_AUTO) return STX_ERR_INVALID;
+    c->canny_mode = mode;
+    c->raw_next = true;
+    c->dense_run = 0;
     return STX_OK;
 }
 int stx_set_timing(stx_ctx* c, int enabled) {

@@ -13,8 +13,6 @@
 // iterates to its local fix-point, then the host launches further passes until a pass
 // changes nothing anywhere (stale reads of a neighbouring tile's words are harmless: the
 // map only ever grows, and the last pass re-checks every tile against final neighbours).
-#include <cstdlib>
-
 #include "stx_internal.h"
 
 namespace stx {
@@ -235,8 +233,10 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
         const uint8_t* fl_prev = tflag + (int64_t)((p - 1) & 1) * tflag_half + tbase;
         uint8_t* fl_cur = tflag + (int64_t)(p & 1) * tflag_half + tbase;
         bool any = false;
-        for (int base = wave * 64; base < tpf; base += nwaves * 64) {
-            const int rem = base + lane;
+        // lane l of wave w looks at tile (j0 + l) * nwaves + w, so that the tiles of a busy region, which are
+        // neighbours in this numbering, are spread over the waves instead of queueing up in one
+        for (int j0 = 0; j0 * nwaves + wave < tpf; j0 += 64) {
+            const int rem = (j0 + lane) * nwaves + wave;
             int f = 0;
             if (rem < tpf) {
                 const int tl = rem / nwords, wx = rem - tl * nwords;
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                any |= hyst_tile(strong, cand, nlines, nwords, ntiles, (int)(tbase + base + l), nullptr, p, tile_count, tflag,
-                                 tflag_half);
+                any |= hyst_tile(strong, cand, nlines, nwords, ntiles, (int)(tbase + (j0 + l) * nwaves + wave), nullptr, p, tile_count,
+                                 tflag, tflag_half);
             }
         }
         if (any && lane == 0) round_changed[round & 1] = 1;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void nms_apply_kernel(unsigned long long* __re
                                                         const uint8_t* __restrict__ gray, int gpitch, int grows, int H,
                                                         int nlines, int nwords, int ntiles, int low, int high,
                                                         uint8_t* __restrict__ sflag, const uint32_t* __restrict__ list,
-                                                        int list_cap, const unsigned int* __restrict__ count, int dbg) {
+                                                        int list_cap, const unsigned int* __restrict__ count) {
     // grid: (blocks per frame, frames); a workgroup reads its frame's count once and walks over the list with the
     // grid's stride, so a frame with a short list costs the others nothing
     const int tpf = ntiles * nwords;
@@ -390,7 +390,6 @@ __global__ __launch_bounds__(256) void nms_apply_kernel(unsigned long long* __re
         const uint32_t item = live ? list[(int64_t)frame * list_cap + i] : list[(int64_t)frame * list_cap + n - 1];
         const int x = (int)(item & 8191u), y = (int)(item >> 13);
         int m, na, nb, slack;
-        if (dbg & 2) { m = (int)item; na = 0; nb = 0; slack = 0; } else
         if (y >= 2 && y + 2 < H && x >= 2 && x + 2 < W) {
             // the 5x5 patch around the pixel, five rows of two aligned words each: every load is issued before the
             // first is used, and a row costs one or two cache lines instead of a line per byte
@@ -453,7 +452,7 @@ __global__ __launch_bounds__(256) void nms_apply_kernel(unsigned long long* __re
             if (lane >= o && k2 == key) { vc |= c2; vs |= s2; }
         }
         const uint32_t knext = __shfl_down(key, 1, 64);
-        if (live && (lane == 63 || knext != key) && !(dbg & 1)) {
+        if (live && (lane == 63 || knext != key)) {
             if (vc) atomicOr(&cand2[idx], vc);
             if (vs) {
                 atomicOr(&strong[idx], vs);
@@ -572,8 +571,7 @@ void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long 
     const int lo = low < -1 ? -1 : (low > 4095 ? 4095 : low), hi = high < -1 ? -1 : (high > 4095 ? 4095 : high);
     const int bpf = (cap + 255) / 256;
     hipLaunchKernelGGL(nms_apply_kernel, dim3((unsigned)(bpf < 32 ? bpf : 32), (unsigned)n_frames), dim3(256), 0, s, strong, cand2,
-                       gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count,
-                       getenv("SIFT_TEXTURE_NMSDBG") ? atoi(getenv("SIFT_TEXTURE_NMSDBG")) : 0);
+                       gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

@@ -204,6 +204,14 @@ class TextureContext:
     def set_chunk_frames(self, n: int):
         self._check(self.lib.stx_set_chunk_frames(self.handle, n), "stx_set_chunk_frames")
 
+    CANNY_MODES = {"dense": 0, "sparse": 1, "auto": 2}
+
+    def set_canny_mode(self, mode: str):
+        """Where Canny's non-maximum suppression runs (same edge map either way): "dense" = on every pixel in the
+        stencil pass, "sparse" = on the pixels a flood of the raw threshold maps reaches, "auto" (default) = sparse
+        while that set stays small."""
+        self._check(self.lib.stx_set_canny_mode(self.handle, self.CANNY_MODES[mode]), "stx_set_canny_mode")
+
     def set_concurrency(self, on: bool):
         self._check(self.lib.stx_set_concurrency(self.handle, 1 if on else 0), "stx_set_concurrency")
 
