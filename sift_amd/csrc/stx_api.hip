@@ -125,7 +125,8 @@ struct stx_ctx {
     // where Canny's non-maximum suppression runs (stx_set_canny_mode; SIFT_TEXTURE_CANNY=dense|sparse|auto)
     int canny_mode = STX_CANNY_AUTO;
     bool raw_next = true;   // auto: what the next chunk does
-    int dense_run = 0;      // auto: dense chunks since the last sparse one (one in RAW_PROBE is tried sparse again)
+    int dense_run = 0;      // auto: dense chunks since the last sparse one
+    int raw_probe = 32;     // auto: dense chunks before the next sparse try
     uint64_t raw_requeued = 0;
     bool timing = false;
     uint32_t timing_kinds = ~0u;       // bit k: launches of kernel family k are bracketed by events while timing is on
@@ -424,7 +425,7 @@ struct ChunkOpts {
     uint8_t* codes = nullptr;  // device, optional [F][H][W]
     bool force_dense = false;
 };
-constexpr int RAW_PROBE = 32;
+constexpr int RAW_PROBE = 32, RAW_PROBE_MAX = 1024;  // auto: dense chunks between two sparse tries, doubling while the tries fail
 constexpr double RAW_MAX_DENSITY = 0.02;  // flooded pixels per pixel above which the suppression goes back into the stencil pass
 
 
@@ -540,7 +541,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     {
         const bool eligible = p.lbp_points == 8 && p.lbp_radius == 1.0 && !opts.codes && !opts.force_dense && !sl.gray.fixed;
         sl.raw = eligible && (c->canny_mode == STX_CANNY_SPARSE || (c->canny_mode == STX_CANNY_AUTO && c->raw_next));
-        if (eligible && c->canny_mode == STX_CANNY_AUTO && !sl.raw && ++c->dense_run >= RAW_PROBE) {
+        if (eligible && c->canny_mode == STX_CANNY_AUTO && !sl.raw && ++c->dense_run >= c->raw_probe) {
             c->raw_next = true;
             c->dense_run = 0;
         }
@@ -801,6 +802,11 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx
             o.codes = sl.src_codes;
             o.force_dense = true;
             ++c->raw_requeued;
+            if (c->canny_mode == STX_CANNY_AUTO) {  // and the next chunks are dense; the next try comes twice as late
+                c->raw_next = false;
+                c->dense_run = 0;
+                c->raw_probe = std::min(c->raw_probe * 2, RAW_PROBE_MAX);
+            }
             sl.spans.swap(c->spans_kept);  // the first attempt's timing spans stay counted
             const int rc = enqueue_chunk(c, sl, sl.src_bgr, sl.src_row_stride, sl.src_frame_stride, sl.F, pr, o);
             if (rc != STX_OK) return rc;
@@ -812,6 +818,9 @@ int finish_chunk(stx_ctx* c, Slot& sl, const Prepared& pr, stx_metrics* out, stx
             if ((double)sl.changed_host[1 + RAW_REACHED - (RAW_GRID_PASSES + RAW_FINISH - 1)] > RAW_MAX_DENSITY * px) {
                 c->raw_next = false;
                 c->dense_run = 0;
+                c->raw_probe = std::min(c->raw_probe * 2, RAW_PROBE_MAX);
+            } else {
+                c->raw_probe = RAW_PROBE;
             }
         }
     }
@@ -1519,6 +1528,7 @@ int stx_set_canny_mode(stx_ctx* c, int mode) {
     c->canny_mode = mode;
     c->raw_next = true;
     c->dense_run = 0;
+    c->raw_probe = RAW_PROBE;
     return STX_OK;
 }
 int stx_set_timing(stx_ctx* c, int enabled) {
