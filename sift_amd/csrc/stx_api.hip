@@ -26,8 +26,11 @@ constexpr int HYST_GRID_PASSES = HYST_FIRST_PASSES;
 // Raw-threshold chunks (see nms_sparse_kernel): the flood of the raw maps keeps its own pass flags behind the
 // ordinary ones: four grid-wide passes, two per-frame finishing launches, and in the last word the size of the
 // flooded set.
-constexpr int RAW_GRID_PASSES = 6, RAW_FINISH = 2, RAW_WORDS = 16, RAW_REACHED = 15;
-constexpr int RAW_SECOND_GRID = 4, RAW_SECOND_PASSES = 6;  // the flood after the suppression: passes queued with the chunk
+constexpr int RAW_GRID_PASSES = 4, RAW_FINISH = 2, RAW_WORDS = 16, RAW_REACHED = 15;
+// The flood after the suppression has a handful of tiles per frame to work on: no grid-wide passes, the per-frame
+// kernel from the start, as pass RAW_SECOND_START (even: the flags it reads as those of the pass before are the second
+// half, where the suppression marked the tiles that hold a strong pixel; changed[RAW_SECOND_START - 1] is preset).
+constexpr int RAW_SECOND_GRID = 0, RAW_SECOND_START = 2, RAW_SECOND_PASSES = 2;
 constexpr int HYST_GROUP = 1;         // further launches per host check when the first batch was not enough
 
 struct DevBuf {
@@ -599,6 +602,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     if (sl.raw) {
         HIPCHK(c, hipMemsetAsync((unsigned int*)sl.changed.p + HYST_MAX_PASSES, 0, (size_t)RAW_WORDS * sizeof(unsigned int), sclr));
         HIPCHK(c, hipMemsetAsync(sl.nmscount.p, 0, (size_t)F * sizeof(unsigned int), sclr));
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)((unsigned int*)sl.changed.p + RAW_SECOND_START - 1), 1, 1, sclr));
         HIPCHK(c, hipMemsetAsync(sl.cand2.p, 0, need[CB_CAND2], sclr));
     }
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
@@ -663,10 +667,11 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
                 launch_hyst_finish(hs, (unsigned long long*)sl.strong.p, (const unsigned long long*)sl.cand.p, F, g, ch1, k,
                                    (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
             launch_nms_sparse(hs, (unsigned long long*)sl.strong.p, (unsigned long long*)sl.cand2.p, (const uint8_t*)sl.gray.p, F, g,
-                              p.canny_low, p.canny_high, (const uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p, (uint32_t*)sl.nmslist.p,
+                              p.canny_low, p.canny_high, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p, (uint32_t*)sl.nmslist.p,
                               (unsigned int*)sl.nmscount.p,
                               ch1 + RAW_GRID_PASSES + RAW_FINISH - 1, ch1 + RAW_REACHED);
             sp.end();
+            sl.passes = RAW_SECOND_START;
         }
         if ((rc = hyst_passes(c, sl, sl.raw ? RAW_SECOND_PASSES : HYST_FIRST_PASSES, g, hs)) != STX_OK) return rc;
     }

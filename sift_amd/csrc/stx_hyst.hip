@@ -317,21 +317,25 @@ __device__ __forceinline__ int patch_mag(uint32_t r0, uint32_t r1, uint32_t r2, 
 }
 __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned long long* __restrict__ strong, int nlines,
                                                                      int nwords, int ntiles, int total_tiles,
-                                                                     const uint32_t* __restrict__ tile_count,
+                                                                     uint32_t* __restrict__ tile_count,
                                                                      uint8_t* __restrict__ sflag,
                                                                      uint32_t* __restrict__ list, int list_cap,
                                                                      unsigned int* __restrict__ count,
-                                                                     unsigned int* __restrict__ unsettled,
-                                                                     unsigned int* __restrict__ reached_total) {
+                                                                     unsigned int* __restrict__ unsettled) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * NMS_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * NMS_WAVES;
     const int tpf = ntiles * nwords;
-    unsigned int reached = 0;
     // lane l of wave w looks at tile (j0 + l) * nwaves + w: the tiles of a busy region are spread over many waves
     for (int j0 = 0; j0 * nwaves + wave < total_tiles; j0 += 64) {
         const int mine = (j0 + lane) * nwaves + wave;
-        if (mine < total_tiles) sflag[mine] = 0;
-        unsigned long long todo = __ballot(mine < total_tiles && tile_count[mine] != 0);
+        uint32_t had = 0;
+        if (mine < total_tiles) {
+            had = tile_count[mine];
+            // the flood that follows counts from zero and starts from the flags the suppression sets
+            tile_count[mine] = 0;
+            sflag[mine] = 0;
+        }
+        unsigned long long todo = __ballot(had != 0);
         while (todo) {
             const int tile_id = (j0 + __ffsll((long long)todo) - 1) * nwaves + wave;
             todo &= todo - 1;
@@ -353,10 +357,7 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned lo
             }
             const uint32_t total = __shfl(inc, 63, 64);
             uint32_t base = 0;
-            if (lane == 0) {
-                base = atomicAdd(&count[frame], total);
-                reached += total;
-            }
+            if (lane == 0) base = atomicAdd(&count[frame], total);
             base = __shfl(base, 0, 64);
             if (base + total > (uint32_t)list_cap) {  // wave-uniform
                 if (lane == 0) *unsettled = 1u;
@@ -367,19 +368,22 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned lo
                 *dst++ = ((uint32_t)(wx * 64 + (__ffsll((long long)w) - 1)) << 13) | (uint32_t)ln;
         }
     }
-    if (lane == 0 && reached) atomicAdd(reached_total, reached);
 }
 __global__ __launch_bounds__(256) void nms_apply_kernel(unsigned long long* __restrict__ strong,
                                                         unsigned long long* __restrict__ cand2,
                                                         const uint8_t* __restrict__ gray, int gpitch, int grows, int H,
                                                         int nlines, int nwords, int ntiles, int low, int high,
                                                         uint8_t* __restrict__ sflag, const uint32_t* __restrict__ list,
-                                                        int list_cap, const unsigned int* __restrict__ count) {
+                                                        int list_cap, const unsigned int* __restrict__ count,
+                                                        unsigned int* __restrict__ reached_total) {
     // grid: (blocks per frame, frames); a workgroup reads its frame's count once and walks over the list with the
     // grid's stride, so a frame with a short list costs the others nothing
     const int tpf = ntiles * nwords;
     const int frame = blockIdx.y;
     const unsigned int n = count[frame];
+    // the size of the flooded set, for the caller's choice of path: one add per frame (adds to one address queue up:
+    // one per tile cost the collecting kernel half of its time)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(reached_total, n);
     if (n > (unsigned int)list_cap) return;  // (an overflowed frame is redone by the caller)
     const uint8_t* gp = gray + (int64_t)frame * grows * gpitch;
     const int W = nlines;
@@ -558,20 +562,22 @@ int nms_list_cap(const Geom& g) {
     return (int)(cap < 1024 ? 1024 : cap);
 }
 void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long long* cand2, const uint8_t* gray, int n_frames,
-                       const Geom& g, int low, int high, const uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
+                       const Geom& g, int low, int high, uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
                        unsigned int* count, unsigned int* unsettled, unsigned int* reached_total) {
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     const int total = (int)half;
     const int cap = nms_list_cap(g);
-    int grid = (total + 64 * NMS_WAVES - 1) / (64 * NMS_WAVES);
-    if (grid > HYST_LATER_GRID) grid = HYST_LATER_GRID;
+    // eight tiles per wave: a tile with flooded pixels costs its wave two trips to memory and an atomic, one after the
+    // other, and the waves that draw several such tiles are what the kernel waits for
+    int grid = (total + 8 * NMS_WAVES - 1) / (8 * NMS_WAVES);
+    if (grid > HYST_MAX_GRID) grid = HYST_MAX_GRID;
     hipLaunchKernelGGL(nms_collect_kernel, dim3(grid), dim3(64 * NMS_WAVES), 0, s, strong, g.W, g.bm_words, g.bm_tiles, total,
-                       tile_count, tflag + half, list, cap, count, unsettled, reached_total);
+                       tile_count, tflag + half, list, cap, count, unsettled);
     // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound (as in the stencil pass)
     const int lo = low < -1 ? -1 : (low > 4095 ? 4095 : low), hi = high < -1 ? -1 : (high > 4095 ? 4095 : high);
     const int bpf = (cap + 255) / 256;
     hipLaunchKernelGGL(nms_apply_kernel, dim3((unsigned)(bpf < 32 ? bpf : 32), (unsigned)n_frames), dim3(256), 0, s, strong, cand2,
-                       gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count);
+                       gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count, reached_total);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

@@ -133,13 +133,14 @@ void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigne
                       const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
 // After a flood of RAW threshold maps (`strong` = the flooded set, tile_count = its size per tile as the flood left it):
 // non-maximum suppression of the pixels in the set from the gray plane.  Leaves the suppressed candidates in `cand2`
-// (zeroed by the caller), "tile holds a strong pixel" in the second half of tflag (what hysteresis pass 0 reads), the
-// suppressed strong pixels in `strong`, and adds the size of the set to *reached_total.
+// (zeroed by the caller), "tile holds a strong pixel" in the second half of tflag (what hysteresis pass 0 reads, and
+// what launch_hyst_finish reads as the flags of an odd pass before it), the suppressed strong pixels in `strong`, zeros
+// in tile_count, and adds the size of the set to *reached_total.
 // list: [n_frames][nms_list_cap(g)] entries, count: [n_frames], zeroed by the caller; *unsettled is set when a frame's
 // set does not fit its list (the maps are then unusable and the caller runs the chunk the ordinary way).
 int nms_list_cap(const Geom& g);
 void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long long* cand2, const uint8_t* gray, int n_frames,
-                       const Geom& g, int low, int high, const uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
+                       const Geom& g, int low, int high, uint32_t* tile_count, uint8_t* tflag, uint32_t* list,
                        unsigned int* count, unsigned int* unsettled, unsigned int* reached_total);
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,
                          const FftPart* fpart, int nfparts, int n_frames, const Geom& g, FrameAcc* acc);
