@@ -5,8 +5,9 @@ one pass) over tools/prof1.py, which analyses FRAMES 1080p frames per dispatch.
 
 Both counters come in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes, so the reads of
 kernels whose loads are 12 bytes per lane or wider (gray, the stencil pass that reads BGR frames, FFT rows
-prefetch aside, FFT cols) are doubled; narrow-load kernels (hysteresis, FFT rows byte/halfword loads) are left
-as counted, so their true read traffic lies between the raw and the doubled figure.
+prefetch aside, FFT cols) are doubled; narrow-load kernels (hysteresis and the suppression on the flooded set, which
+is counted with it, FFT rows byte/halfword loads) are left as counted, so their true read traffic lies between the raw
+and the doubled figure.  "clears" are the runtime's fill kernels (accumulators, flags, the second candidate map).
 """
 import collections
 import csv
@@ -16,7 +17,9 @@ import sys
 # (substring of the kernel name, group, loads are wide); the first match counts.  stencil_kernel<.., .., true> reads
 # the BGR frames with 12-byte loads, stencil_kernel<.., .., false> the gray plane with 16-byte loads
 GROUPS = (("gray_kernel", "gray", True), ("stencil_kernel", "stencil", True), ("lbp_generic", "lbp_generic", False),
-          ("hyst_pass_kernel", "hysteresis", False), ("rows_kernel", "fft_rows", False), ("cols_kernel", "fft_cols", True),
+          ("hyst_pass_kernel", "hysteresis", False), ("hyst_finish_kernel", "hysteresis", False),
+          ("nms_collect_kernel", "hysteresis", False), ("nms_apply_kernel", "hysteresis", False),
+          ("fillBufferAligned", "clears", False), ("rows_kernel", "fft_rows", False), ("cols_kernel", "fft_cols", True),
           ("frame_reduce", "reduce", False))
 
 

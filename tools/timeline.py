@@ -7,7 +7,7 @@ import csv
 import sys
 
 NAMES = (("stencil", "stencil"), ("gray_kernel", "gray"), ("rows_kernel", "fft_rows"), ("cols_kernel", "fft_cols"),
-         ("hyst_pass", "hysteresis"), ("hyst_finish", "hysteresis"), ("frame_reduce", "reduce"), ("synth", "synth"),
+         ("hyst_pass", "hysteresis"), ("hyst_finish", "hysteresis"), ("nms_collect", "suppression"), ("nms_apply", "suppression"), ("frame_reduce", "reduce"), ("synth", "synth"),
          ("copyBuffer", "copy"), ("fillBuffer", "fill"), ("fft64", "fft64"))
 
 
