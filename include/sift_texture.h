@@ -231,7 +231,8 @@ int stx_get_timing(stx_ctx* ctx, stx_timing* out, int reset);
  * STX_CANNY_DENSE: in the stencil pass, on every pixel.  STX_CANNY_SPARSE: the stencil pass leaves the raw double
  * threshold, a flood of those maps finds the pixels an edge can reach, the suppression runs on those only (a fraction
  * of a percent of a camera frame), the ordinary hysteresis follows; a chunk whose flood does not settle in its passes,
- * or reaches more than 4 % of a frame, goes through again the dense way.  STX_CANNY_AUTO (default): sparse while the
+ * or reaches more than 4 % of a frame, goes through again the dense way.  STX_CANNY_AUTO (default): sparse for chunks
+ * of 64 Mpixel and more (a call on a few frames is made of launches, and the sparse path has more of them) while the
  * flooded set stays below 2 % of the pixels, dense otherwise, with one chunk in 32 tried sparse again (one in 64,
  * 128 ... 1024 while the tries keep failing).  Calls that ask
  * for code planes, LBP radii other than (8,1) and the allocation-free entry point are always dense.  The environment
