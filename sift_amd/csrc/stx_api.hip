@@ -624,7 +624,8 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
                        (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, sl.raw);
         sp.end();
     }
-    HIPCHK(c, hipEventRecord(sl.stencil_done, s));
+    // (a raw chunk's second-stream work waits for the row pass instead: no event between the stencil and the row pass)
+    if (!(sl.raw && fused_flow)) HIPCHK(c, hipEventRecord(sl.stencil_done, s));
     if (!lbp81) {
         Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 2, s);
         const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, (uint32_t*)sl.lpart.p, acc,
