@@ -552,7 +552,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 // re-evaluates its own pixels here.
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(__popc(pend)), 63);
                 if (tot > DENSE_MIN) {
-                    if (!BORDER) {
+                    {
                         // Flat neighbourhoods first: where the four columns x-1 .. x+2 hold one value over three
                         // consecutive rows, both pixels of the middle row have all axis bits set and their diagonal
                         // bits come from the table instead of trips through the fp64 sequence.  Rolled loops: this
@@ -561,11 +561,15 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                         const uint8_t* tp = tile + (yb - 1 - y0 + 2) * LPITCH + (x - x0 + GRAY_XOFF) - 1;
                         uint8_t* cvb = reinterpret_cast<uint8_t*>(wq) + lane * BLOCK_ROWS;
                         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0, elig = 0;
+                        // (on a border strip the tile holds mirrored pixels where LBP sees zeros: a row outside the
+                        // image, or a lane whose four columns are not all inside it, is never flat)
+                        const bool cols_in = !BORDER || (x >= 1 && x + 2 < W);
 #pragma unroll 1
                         for (int r = 0; r < BLOCK_ROWS + 2; ++r) {
                             const uint32_t b0 = tp[r * LPITCH], b1 = tp[r * LPITCH + 1], b2 = tp[r * LPITCH + 2],
                                            b3 = tp[r * LPITCH + 3];
-                            const uint32_t f = (((b0 ^ b1) | (b1 ^ b2) | (b2 ^ b3)) == 0) ? 1u : 0u;
+                            uint32_t f = (((b0 ^ b1) | (b1 ^ b2) | (b2 ^ b3)) == 0) ? 1u : 0u;
+                            if (BORDER && !(cols_in && yb - 1 + r >= 0 && yb - 1 + r < H)) f = 0u;
                             if (r >= 2 && (f & f1 & f0) != 0 && b0 == v1 && v1 == v0) elig |= 1u << (r - 2);
                             if (r >= 1 && r <= BLOCK_ROWS) cvb[r - 1] = (uint8_t)b1;
                             f0 = f1; v0 = v1; f1 = f; v1 = b0;
