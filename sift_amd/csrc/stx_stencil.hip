@@ -265,19 +265,24 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     const int ys = y0 + wv * WAVE_ROWS;
     const uint32_t vm = BORDER ? ((x < W ? 0xFFFFu : 0u) | (x + 1 < W ? 0xFFFF0000u : 0u)) : 0xFFFFFFFFu;
 
-    // Border strips build the Canny (replicate) and LBP (zero) views with per-lane byte selectors over
-    // the six window bytes x-2 .. x+3.
-    uint32_t selC[3] = {0, 0, 0}, selZ[3] = {0, 0, 0};
+    // The tile holds BORDER_REFLECT_101 copies outside the image; border strips make the other two views from the pixel
+    // pairs (x-1,x) (x,x+1) (x+1,x+2) every row builds anyway: the LBP view (zeros outside) by one AND each with a
+    // per-lane mask, the Canny view (the border pixel repeated) by one byte permute each over two neighbouring pairs,
+    // with a per-lane selector that is the identity away from the image's left and right edge.
+    uint32_t selC[3] = {0, 0, 0}, maskZ[3] = {0, 0, 0};
     if (BORDER) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int e0 = x + k - 1, e1 = e0 + 1;
-            const int c0 = iclamp(iclamp(e0, 0, W - 1) - (x - 2), 0, 5);
-            const int c1 = iclamp(iclamp(e1, 0, W - 1) - (x - 2), 0, 5);
-            selC[k] = (uint32_t)c0 | 0x0c00u | ((uint32_t)c1 << 16) | 0x0c000000u;
-            const int z0 = (e0 >= 0 && e0 < W) ? e0 - (x - 2) : 0x0c;
-            const int z1 = (e1 >= 0 && e1 < W) ? e1 - (x - 2) : 0x0c;
-            selZ[k] = (uint32_t)z0 | 0x0c00u | ((uint32_t)z1 << 16) | 0x0c000000u;
+            // sources of pair k: k = 0: {low = (x-1,x), high = (x,x+1)}, k = 1, 2: {low = (x,x+1), high = (x+1,x+2)};
+            // a pixel `off` columns right of the low pair's first one sits in byte 0, 2 or 6 of the two registers
+            const int base = k == 0 ? x - 1 : x;
+            auto byte_of = [&](int e) {
+                const int off = iclamp(e, 0, W - 1) - base;
+                return off == 1 ? 2 : (off == 2 ? 6 : 0);  // (out of reach only for lanes wholly outside the image)
+            };
+            selC[k] = (uint32_t)byte_of(e0) | 0x0c00u | ((uint32_t)byte_of(e1) << 16) | 0x0c000000u;
+            maskZ[k] = ((e0 >= 0 && e0 < W) ? 0xFFFFu : 0u) | ((e1 >= 0 && e1 < W) ? 0xFFFF0000u : 0u);
         }
     }
 
@@ -323,19 +328,18 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             o.sm = pk_mad<2>(t0, s1);
         } else {
             const int ry = ys - 2 + rel;
-            const bool rin = ry >= 0 && ry < H;
-            const uint32_t AB = A | (B << 16);
-            zm1 = rin ? perm(C, AB, selZ[0]) : 0u;
-            o.z0 = rin ? perm(C, AB, selZ[1]) : 0u;
-            zp1 = rin ? perm(C, AB, selZ[2]) : 0u;
-            uint32_t cAB = AB, cC = C;
-            if (!rin) {  // wave-uniform: the Canny view repeats the first / last image row
+            uint32_t um1 = tm1, u0 = t0, up1 = tp1;  // the pairs the Canny view is cut from
+            if (ry >= 0 && ry < H) {  // wave-uniform
+                zm1 = tm1 & maskZ[0]; o.z0 = t0 & maskZ[1]; zp1 = tp1 & maskZ[2];
+            } else {
+                // a row above or below the image: zeros for LBP, the first / last image row again for Canny
+                zm1 = 0u; o.z0 = 0u; zp1 = 0u;
                 const uint16_t* q = reinterpret_cast<const uint16_t*>(tile + (iclamp(ry, 0, H - 1) - y0 + 2) * LPITCH +
                                                                       2 * lane + 2);
-                cAB = (uint32_t)q[0] | ((uint32_t)q[1] << 16);
-                cC = q[2];
+                const uint32_t A2 = q[0], B2 = q[1], C2 = q[2];
+                um1 = perm(B2, A2, SEL_CROSS); u0 = perm(0, B2, SEL_PAIR); up1 = perm(C2, B2, SEL_CROSS);
             }
-            const uint32_t cm1 = perm(cC, cAB, selC[0]), c0 = perm(cC, cAB, selC[1]), cp1 = perm(cC, cAB, selC[2]);
+            const uint32_t cm1 = perm(u0, um1, selC[0]), c0 = perm(up1, u0, selC[1]), cp1 = perm(up1, u0, selC[2]);
             o.d = pk_sub(cp1, cm1);
             o.sm = pk_mad<2>(c0, cm1 + cp1);
         }
