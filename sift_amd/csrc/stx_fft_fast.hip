@@ -914,15 +914,30 @@ __global__ __launch_bounds__(P::COLS_THREADS) void cols_kernel(ColsArgs a) {
     double ls = sink.ls, ls2 = sink.ls2;
     float t1 = sink.t1, t2 = sink.t2, e2 = sink.e2;
     if (k >= a.fwh) { ls = 0.0; ls2 = 0.0; t1 = 0.f; t2 = 0.f; e2 = 0.f; }  // columns past the half spectrum hold no data
-#pragma unroll
-    for (int o = LPT / 2; o > 0; o >>= 1) {
-        ls += __shfl_xor(ls, o, 64);
-        ls2 += __shfl_xor(ls2, o, 64);
-        t1 += __shfl_xor(t1, o, 64);
-        t2 += __shfl_xor(t2, o, 64);
-        e2 += __shfl_xor(e2, o, 64);
+    // Sums over the LPT lanes of a transform, left in its last lane: shifts by 1, 2, 4, 8 inside each row of 16 lanes,
+    // then lane 15 of a row into the next row, then lane 31 into the upper half -- operands fetched from the other
+    // lane inside the vector unit.  (As __shfl_xor butterflies these were 42 trips through the LDS crossbar per
+    // transform, half of the kernel's LDS instructions.)
+#define STX_LANE_SUMS(CTRL, ROWS)                                                                                   \
+    {                                                                                                              \
+        const double a_ = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(ls), CTRL, ROWS, 0xf, false),   \
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(ls), CTRL, ROWS, 0xf, false));  \
+        const double b_ = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(ls2), CTRL, ROWS, 0xf, false),  \
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(ls2), CTRL, ROWS, 0xf, false)); \
+        const float c_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t1), CTRL, ROWS, 0xf, false));     \
+        const float d_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t2), CTRL, ROWS, 0xf, false));     \
+        const float e_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e2), CTRL, ROWS, 0xf, false));     \
+        ls += a_; ls2 += b_; t1 += c_; t2 += d_; e2 += e_;                                                         \
     }
-    if (t == 0) {
+    static_assert(LPT == 16 || LPT == 32 || LPT == 64, "a transform's lanes are whole rows of sixteen");
+    STX_LANE_SUMS(0x111, 0xf)  // row_shr:1
+    STX_LANE_SUMS(0x112, 0xf)  // row_shr:2
+    STX_LANE_SUMS(0x114, 0xf)  // row_shr:4
+    STX_LANE_SUMS(0x118, 0xf)  // row_shr:8
+    if (LPT >= 32) STX_LANE_SUMS(0x142, 0xa)  // row_bcast:15
+    if (LPT == 64) STX_LANE_SUMS(0x143, 0xc)  // row_bcast:31
+#undef STX_LANE_SUMS
+    if (t == LPT - 1) {
         // columns 0 and (even W) W/2 are their own mirror images; every other column stands for two
         const double wgt = (k >= a.fwh) ? 0.0 : ((k == 0 || ((a.fw & 1) == 0 && k == a.fw / 2)) ? 1.0 : 2.0);
         a.part[((int64_t)frame * a.nkb + kb) * cbw + c] = FftPart{wgt * ls, wgt * ls2, wgt * (double)t1, wgt * (double)t2, wgt * (double)e2};
