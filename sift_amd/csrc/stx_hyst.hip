@@ -21,6 +21,19 @@ __device__ __forceinline__ unsigned long long brev64(unsigned long long v) {
     return ((unsigned long long)__brev((uint32_t)v) << 32) | (unsigned long long)__brev((uint32_t)(v >> 32));
 }
 
+// A word from the neighbouring lane without a trip through the LDS crossbar: lane i takes lane i-1's v (lane 0 takes
+// `edge`), or lane i+1's (lane 63 takes `edge`) -- the tile's halo lines slot in where the shift has no source.
+__device__ __forceinline__ unsigned long long from_lane_below(unsigned long long v, unsigned long long edge) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)edge, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(edge >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32);
+}
+__device__ __forceinline__ unsigned long long from_lane_above(unsigned long long v, unsigned long long edge) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)edge, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(edge >> 32), (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
+    return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32);
+}
+
 // all bits of the candidate runs in c that contain a bit of x (x subset of c)
 __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, unsigned long long x) {
     const unsigned long long up = (c ^ (c + x)) & c;
@@ -171,19 +184,15 @@ __device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ stron
         }
         return false;
     }
-    unsigned long long upL = __shfl_up(Lw, 1, 64), dnL = __shfl_down(Lw, 1, 64);
-    unsigned long long upR = __shfl_up(Rw, 1, 64), dnR = __shfl_down(Rw, 1, 64);
-    if (lane == 0) { upL = Tl; upR = Tr; }
-    if (lane == 63) { dnL = Bl; dnR = Br; }
+    const unsigned long long upL = from_lane_below(Lw, Tl), dnL = from_lane_above(Lw, Bl);
+    const unsigned long long upR = from_lane_below(Rw, Tr), dnR = from_lane_above(Rw, Br);
     // pixels of the neighbouring words that touch this word's first / last pixel
     const unsigned long long carry = ((upL | Lw | dnL) >> 63) | (((upR | Rw | dnR) & 1ull) << 63);
 
     const unsigned long long orig = S;
     bool any;
     do {
-        unsigned long long up = __shfl_up(S, 1, 64), dn = __shfl_down(S, 1, 64);
-        if (lane == 0) up = To;
-        if (lane == 63) dn = Bo;
+        const unsigned long long up = from_lane_below(S, To), dn = from_lane_above(S, Bo);
         const unsigned long long A = S | up | dn;
         const unsigned long long D = A | (A << 1) | (A >> 1) | carry;
         const unsigned long long seeds = (S | (C & D)) & C;
