@@ -204,10 +204,16 @@ __device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ stron
     const bool ch = S != orig;
     if (ch) sb[ln] = S;
     const bool tile_changed = __any(ch);
+    // the tile's count: shifts by 1, 2, 4, 8 inside each row of 16 lanes, lane 15 of a row into the next row, lane 31
+    // into the upper half; lane 63 ends up with the total and does the bookkeeping
     uint32_t cnt = __popcll(S);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) {
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x111, 0xf, 0xf, false);
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x112, 0xf, 0xf, false);
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x114, 0xf, 0xf, false);
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x118, 0xf, 0xf, false);
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x142, 0xa, 0xf, false);
+    cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x143, 0xc, 0xf, false);
+    if (lane == 63) {
         // a flag, not a count: every writer stores the same value, so a plain store is enough
         if (tile_changed && changed) changed[pass] = 1u;
         fl_cur[tl * nwords + wx] = tile_changed ? 1 : 0;
