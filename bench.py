@@ -39,6 +39,9 @@ CONFIGS = {
     "720p": dict(frames=150, h=720, w=1280, fft=0, extended=False, row="configs[0] frame size, on the GPU"),
     "crops256": dict(frames=4096, h=256, w=256, fft=0, extended=False, row="configs[1]"),
     "4k_multiradius": dict(frames=40, h=2160, w=3840, fft=512, extended=True, row="configs[4]"),
+    # 10,000 clips over all ranks by video id; a clip exists only while it is in flight (generated on the device
+    # from (seed, video id) beside the analysis of the clip before it, three rotating buffers per rank)
+    "clips10k": dict(frames=150, h=1080, w=1920, fft=0, extended=False, row="configs[3]", total_clips=10000),
 }
 
 
@@ -63,9 +66,23 @@ GROUPS = {"texture": ("gray", "stencil", "lbp_generic", "extended"), "hysteresis
           "fft": ("fft_rows", "fft_cols")}
 
 
+def kernel_algorithmic_bytes(h: int, w: int, fh: int, fw: int, separate_gray: bool) -> dict:
+    """The same account split by kernel family (it sums to algorithmic_bytes()["path"]): the stencil pass reads the
+    BGR frame and writes the Canny map (with a separate gray pass the 3HW belong to that pass), the hysteresis
+    kernels read the map, the row pass writes the half spectrum and the column pass reads it.  The kernels of the
+    extended statistics add nothing to the path's account (same tile, larger halo); as kernels of their own they
+    are charged the one gray-plane read they cannot avoid."""
+    spec = 8 * fh * (fw // 2 + 1)
+    if spec <= 160 * 1024:
+        spec = 0
+    return {"gray": 3 * h * w if separate_gray else 0, "stencil": (h * w if separate_gray else 3 * h * w) + h * w,
+            "hysteresis": h * w, "fft_rows": spec, "fft_cols": spec, "lbp_generic": h * w, "extended": h * w,
+            "quality": h * w}
+
+
 def measured_traffic(h: int, w: int):
     """Per-frame HBM bytes per kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    for name in ("r2_traffic.json", "r1_d_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_d_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -94,7 +111,8 @@ def self_launch(args) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps per GPU (0 = 40; for clips10k: this rank's share of the 10,000 clips)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="1080p")
     ap.add_argument("--frames", type=int, default=0, help="frames per step (0 = the config's)")
@@ -148,6 +166,9 @@ def main() -> None:
     from sift_amd.texture import TextureContext
 
     cfg = CONFIGS[args.config]
+    streaming = "total_clips" in cfg  # clips are generated inside the loop and never kept
+    if args.steps <= 0:
+        args.steps = (cfg["total_clips"] + world - 1) // world if streaming else 40
     h, w = args.height or cfg["h"], args.width or cfg["w"]
     nf = args.frames or cfg["frames"]
     fh = fw = cfg["fft"]
@@ -161,9 +182,10 @@ def main() -> None:
         params.fft_h, params.fft_w = fh, fw
     clip_bytes = nf * h * w * 3
     total_steps = max(args.steps, 1)
-    n_clips = int(max(2, min(total_steps, MAX_RESIDENT_BYTES // clip_bytes)))
+    n_clips = 3 if streaming else int(max(2, min(total_steps, MAX_RESIDENT_BYTES // clip_bytes)))
     clips = [torch.empty(clip_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_clips)]
-    seed = 0x5EED0000 + 2
+    seed = 0x5EED0000 + (3 if streaming else 2)
+    gen_in_loop = [streaming]  # (a list: the generation-free comparison run below switches it off)
 
     def synth(t, video: int) -> None:
         # the generator numbers at most 1024 frames per video: longer batches continue in further videos
@@ -186,6 +208,8 @@ def main() -> None:
 
     def step(i: int, keep: int = -1) -> None:
         ptr = clips[i % n_clips].data_ptr()
+        if gen_in_loop[0]:
+            ctx.synth_device_async(ptr, KIND_ID[args.kind], seed, i * world + rank, 0, nf, h, w)
         if cfg["extended"]:
             rc = ctx.lib.stx_analyze_extended_batch_device(ctx.handle, ptr, nf, h, w, 3 * w, 3 * w * h,
                                                            C.byref(params) if params is not None else None, out, ext)
@@ -195,8 +219,9 @@ def main() -> None:
         if keep >= 0:
             keep_rows(out, keep)
 
-    # the extended entry point has no asynchronous form, and a clip must fit one asynchronous submission
-    pipelined = not (args.blocking or cfg["extended"] or nf > ctx.max_async_frames(h, w))
+    # a clip must fit one asynchronous submission
+    pipelined = not (args.blocking or nf > ctx.max_async_frames(h, w))
+    exts = [(StxExtended * nf)() for _ in range(2)] if cfg["extended"] else None
 
     def run_steps(n: int, keep: bool) -> None:
         """n steps; unless --blocking, software-pipelined two deep through the asynchronous entry point: while
@@ -207,7 +232,15 @@ def main() -> None:
             return
         pending = None
         for i in range(n):
-            t = ctx.submit_device(clips[i % n_clips].data_ptr(), nf, h, w, outs[i % 2], params)
+            ptr = clips[i % n_clips].data_ptr()
+            if gen_in_loop[0]:
+                # this buffer's last reader (clip i - 3) was collected two iterations ago; the generator runs beside
+                # the kernels of clip i - 1, which the device is working on now
+                ctx.synth_device_async(ptr, KIND_ID[args.kind], seed, i * world + rank, 0, nf, h, w)
+            if cfg["extended"]:
+                t = ctx.submit_device_extended(ptr, nf, h, w, outs[i % 2], exts[i % 2], params)
+            else:
+                t = ctx.submit_device(ptr, nf, h, w, outs[i % 2], params)
             if pending is not None:
                 ctx.wait(pending[0])
                 if keep:
@@ -240,10 +273,26 @@ def main() -> None:
     ctx.set_concurrency(True)
     solo_chunks = max(solo["kernels"]["stencil"]["launches"], 1)  # the stencil kernel runs once per chunk of frames
     solo_ms = {g: sum(solo["kernels"][k]["ms"] for k in ks) / solo_chunks for g, ks in GROUPS.items()}
-    dom = max(GROUPS, key=lambda g: solo_ms[g])
+    # The dominant kernel: the single kernel family with the longest duration per chunk (the hysteresis family is a
+    # dozen short launches, the others are one launch per chunk each).
+    kab = kernel_algorithmic_bytes(h, w, fh, fw, separate_gray=solo["kernels"]["gray"]["launches"] > 0)
+    solo_kernel_ms = {k: v["ms"] / solo_chunks for k, v in solo["kernels"].items() if v["launches"] and kab.get(k)}
+    dom = max(solo_kernel_ms, key=lambda k: solo_kernel_ms[k])
     run_steps(args.warmup, keep=False)
+    analysis_only = None
+    if streaming:
+        # the same pipeline over the three clips left in the buffers, nothing generated: what the analysis alone does
+        gen_in_loop[0] = False
+        run_steps(4, keep=False)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        run_steps(40, keep=False)
+        torch.cuda.synchronize()
+        analysis_only = 40 * nf / (time.perf_counter() - ta)
+        gen_in_loop[0] = True
+        run_steps(3, keep=False)
     ctx.get_timing(reset=True)
-    ctx.set_timing(True, kinds=None if args.time_all_kernels else GROUPS[dom])
+    ctx.set_timing(True, kinds=None if args.time_all_kernels else (dom,) + (("synth",) if streaming else ()))
     sync()
     t0 = time.perf_counter()
     run_steps(args.steps, keep=True)
@@ -266,11 +315,18 @@ def main() -> None:
         fps = frames_total / dt
         ab = algorithmic_bytes(h, w, fh, fw)
         kt = timing["kernels"]
-        # frames per launch of the dominant group's kernels in the timed region (they run once per chunk)
-        chunks = max(max(kt[k]["launches"] for k in GROUPS[dom]), 1)
+        # frames per launch of the dominant kernel in the timed region (it runs once per chunk; the generic LBP and
+        # hysteresis families count several launches per chunk, which the solo clip tells)
+        per_chunk = max(solo["kernels"][dom]["launches"] // solo_chunks, 1)
+        chunks = max(kt[dom]["launches"] // per_chunk, 1)
         frames_per_launch = timing["frames"] / chunks
-        # device time of each kernel group per chunk (sum of its kernels' HIP-event durations)
-        group_ms = {g: sum(kt[k]["ms"] for k in ks) / chunks for g, ks in GROUPS.items()}
+        dom_ms = kt[dom]["ms"] / chunks
+        dom_gbs = kab[dom] * frames_per_launch / (dom_ms * 1e-3) / 1e9
+        dom_gbs_solo = kab[dom] * (solo["frames"] / solo_chunks) / (solo_kernel_ms[dom] * 1e-3) / 1e9
+        # device time of each kernel group per chunk in the timed region (sum of its kernels' HIP-event durations):
+        # known only when every kernel carried events
+        group_ms = {g: (sum(kt[k]["ms"] for k in ks) / chunks if args.time_all_kernels else 0.0)
+                    for g, ks in GROUPS.items()}
         solo_fpl = solo["frames"] / solo_chunks
         groups = {}
         for g in GROUPS:
@@ -286,7 +342,7 @@ def main() -> None:
         mt = measured_traffic(h, w)
         traffic = None
         if mt is not None:
-            traffic = sum(mt[k]["total"] for k in GROUPS[dom] if k in mt) * frames_per_launch
+            traffic = mt[dom]["total"] * frames_per_launch if dom in mt else None
         result = {
             "metric": "texture-analysis frames/sec (whole node) at 1080p + achieved HBM GB/s % of peak",
             "value": fps,
@@ -308,20 +364,27 @@ def main() -> None:
                                    + (", LBP at (8,1) (16,2) (24,3) + Sobel / blockiness sums" if cfg["extended"] else "")
                                    + f" (BASELINE {cfg['row']})",
                        "frames_per_step_per_gpu": nf, "height": h, "width": w, "sharding": "by clip, one rank per GPU",
-                       "distinct_clips_per_gpu": n_clips, "video_id": "step * world + rank",
+                       "distinct_clips_per_gpu": args.steps if streaming else n_clips, "video_id": "step * world + rank",
+                       "clips_resident_per_gpu": n_clips,
                        "submission": "blocking" if not pipelined else "two clips in flight (stx_submit_batch_device / stx_wait)",
                        "untimed_steps_before_warmup": PREWARM_STEPS},
             "roofline": {
-                "bound": "hbm", "kernel": dom + " (" + groups[dom]["kernels"] + ")",
-                "achieved": groups[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": groups[dom]["frac"], "traffic": traffic,
-                "frac_serialized": groups[dom]["frac_serialized"],
-                "algorithmic_bytes_per_frame": ab[dom], "frames_per_launch": frames_per_launch,
-                "avg_launch_ms": groups[dom]["avg_launch_ms"],
-                "note": "dominant group = the one with the longest serialized time (one clip before the timed "
-                        "region, every kernel alone on the device with an event pair around it: *_serialized); in "
-                        "the timed region only the dominant group's kernels carry events (--time-all-kernels: all), "
-                        "and their durations include whatever runs beside them on the other stream",
+                "bound": "hbm", "kernel": dom,
+                "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_serialized": dom_gbs_solo / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_frame": kab[dom], "frames_per_launch": frames_per_launch,
+                "avg_launch_ms": dom_ms,
+                "avg_launch_ms_serialized": solo_kernel_ms[dom],
+                "note": "dominant kernel = the single kernel with the longest serialized duration (one clip before "
+                        "the timed region, every kernel alone on the device with an event pair around it: "
+                        "*_serialized); in the timed region only that kernel carries events (--time-all-kernels: "
+                        "all), on the stream it is launched on, and its durations include whatever runs beside it "
+                        "on the other stream; 'groups' and 'path' give the same account for kernel groups "
+                        "(serialized) and for the whole job",
+                "kernels_serialized": {k: {"ms_per_launch_group": v, "algorithmic_bytes_per_frame": kab[k],
+                                           "frac": kab[k] * (solo["frames"] / solo_chunks) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                       for k, v in solo_kernel_ms.items()},
                 "groups": groups,
                 "path": {"algorithmic_bytes_per_frame": ab["path"], "achieved": path_gbs,
                          "frac": path_gbs / HBM_PEAK_GBS},
@@ -331,7 +394,20 @@ def main() -> None:
             "fft64_frames_in_timed_region": timing["fft64_frames"],
             "mean_texture_score": float(all_rows[..., 5].mean()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if streaming:
+            result["config"]["input"] = ("generated on the device inside the timed region, clip i beside the analysis "
+                                         "of clip i-1 (stx_synth_device_async); 'value' includes the generation")
+            synth_ms = kt["synth"]["ms"] / max(kt["synth"]["launches"], 1)
+            result["streaming"] = {
+                "clips_total": world * args.steps,
+                "frames_per_s_generation_included": fps,
+                "frames_per_s_analysis_only_rank0": analysis_only,
+                "synth_kernel_ms_per_clip_in_situ": synth_ms,
+                "synth_store_GBps": clip_bytes / (synth_ms * 1e-3) / 1e9 if synth_ms > 0 else None,
+            }
+            if not args.no_cpu_baseline:
+                result["streaming"]["spot_check"] = spot_check(all_rows, args.kind, seed, h, w, nf)
+        elif world == 1 and not args.no_cpu_baseline:
             sample = min(nf, 150)
             frames = ctx.d2h(clips[0].data_ptr(), sample * h * w * 3).reshape(sample, h, w, 3)
             result["cpu_baseline"] = cpu_baseline(frames, rows[0], args.cpu_seconds * (0.7 if args.config == "1080p" else 1.0),
@@ -348,6 +424,29 @@ def main() -> None:
     ctx.close()
 
 
+def spot_check(all_rows: np.ndarray, kind: str, seed: int, h: int, w: int, nf: int) -> dict:
+    """Rows of a few late video ids of a streaming run against frames regenerated on the host (sift_amd.synth, the
+    generator's numpy form) and analysed by the C oracle: the clip the GPU analysed at step i is the clip of video i."""
+    from oracle import texture_oracle as O
+    from sift_amd.synth import synth_frame
+
+    co = O.COracle()
+    n_videos = all_rows.shape[0]
+    vids = sorted({v for v in (51, 52 + (n_videos - 52) // 2, n_videos - 1) if 0 <= v < n_videos})
+    if not vids:
+        vids = [n_videos - 1]
+    worst, checked = 0.0, []
+    for v in vids:
+        for f in sorted({0, nf // 2, nf - 1}):
+            m = co.analyze_frame(synth_frame(kind, seed, v, f, h, w))
+            ref = np.array([m.lbp_variance, m.noise_level, m.compression_artifacts, m.edge_density, m.frequency_anomaly,
+                            m.texture_score])
+            rel = np.abs(all_rows[v, f] - ref) / np.maximum(np.abs(ref), 1e-12)
+            worst = max(worst, float(rel.max()))
+            checked.append([int(v), int(f)])
+    return {"video_frame_pairs": checked, "max_rel_diff_vs_oracle": worst, "ok": worst <= 1e-4}
+
+
 def dry_run(args) -> int:
     """STX_BENCH_DRYRUN=1: the launch, sharding and gather of a multi-rank run without any GPU work (rows are a
     function of the video id), over gloo -- what a CPU-only machine can check of --gpus N."""
@@ -361,6 +460,8 @@ def dry_run(args) -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         dist.init_process_group("gloo")
+    if args.steps <= 0:
+        args.steps = 40
     nf = args.frames or 4
     rows = np.zeros((args.steps, nf, 6), np.float64)
     for i in range(args.steps):

@@ -125,15 +125,17 @@ int stx_analyze_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames,
                              int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
                              stx_metrics* out);
 
-/* stx_analyze_batch_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc); it has no counterpart in the reference.  The call itself allocates nothing, on
- * the device or the host: every intermediate (gray planes, edge maps, spectra, partial sums, twiddle tables, the
+/* stx_analyze_batch_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
+ * processes in which another thread is capturing a HIP graph); it has no counterpart in the reference.  The call runs
+ * eagerly and synchronises with the context's streams like stx_analyze_batch_device (it cannot itself be captured
+ * into a graph), but allocates nothing, on the device or the host: every intermediate (gray planes, edge maps, spectra, partial sums, twiddle tables, the
  * fp64 workspace of stx_params.fft_exact) lives in a static device array of STX_NOALLOC_SCRATCH_BYTES that each GPU
  * the library runs on holds until the process ends; streams, events and pinned staging are created by stx_create.
  * Frames go through the array at most 64 at a time.  Limits: LBP at (P=8, R=1) only, no quality_stats, and one
  * frame's workspace must fit the array (1080p and 4K frames do; STX_ERR_UNSUPPORTED with a message otherwise).
- * Results equal stx_analyze_batch_device's.  All contexts of one GPU share the array: calls that overlap on one GPU
- * race (one call at a time per GPU). */
+ * Results equal stx_analyze_batch_device's.  All contexts of one GPU share the array, one call at a time per GPU: a
+ * call that starts while another allocation-free call is running on the same GPU (from another thread, through
+ * another context) returns STX_ERR_INVALID instead of racing with it. */
 #define STX_NOALLOC_SCRATCH_BYTES (128u << 20)
 int stx_analyze_batch_device_noalloc(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w,
                                      int64_t row_stride_bytes, int64_t frame_stride_bytes, const stx_params* params,
@@ -165,6 +167,14 @@ int stx_debug_planes(stx_ctx* ctx, const uint8_t* bgr, int h, int w, int64_t row
  * integer arithmetic as sift_amd/synth.py).  kind: 0 noise, 1 natural, 2 ramp, 3 flat, 4 tie, 5 step. */
 int stx_synth_device(stx_ctx* ctx, uint8_t* bgr_dev, int kind, uint64_t seed, uint32_t video, uint32_t frame0,
                      int n_frames, int h, int w);
+
+/* The same generator without the wait (no counterpart in the reference): the frames are written by the time any
+ * analysis call made on this context afterwards reads them -- the generator is queued on the stream those calls
+ * start on -- and until then it runs beside the context's other work, so a job can make clip i+1 while clip i is
+ * analysed and never hold more than the clips in flight.  bgr_dev must not be read by the host, or freed, before a
+ * later call on the context has returned (or stx_get_timing, which waits for the generator's timing events). */
+int stx_synth_device_async(stx_ctx* ctx, uint8_t* bgr_dev, int kind, uint64_t seed, uint32_t video, uint32_t frame0,
+                           int n_frames, int h, int w);
 
 /* Device / pinned-host buffers for callers without their own allocator. */
 int stx_device_alloc(stx_ctx* ctx, uint64_t bytes, void** out);
@@ -204,6 +214,12 @@ int stx_analyze_extended_frames(stx_ctx* ctx, const uint8_t* const* frames, int 
                                 const stx_params* params, stx_metrics* out, stx_extended* ext);
 int stx_analyze_extended_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
                                       int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext);
+
+/* Asynchronous form of stx_analyze_extended_batch_device: a ticket for stx_wait, as stx_submit_batch_device; ext must
+ * stay valid until stx_wait returns, like out. */
+int stx_submit_extended_batch_device(stx_ctx* ctx, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                     int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext,
+                                     int* ticket);
 
 /* Frame preparation of the CNN branch: replaces PassiveChecker._preprocess_frame
  * (app/passive_checker.py:393-418), called per frame at :432 from the loop at :473 -- BGR -> RGB, cv2.resize to

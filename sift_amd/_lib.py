@@ -26,7 +26,8 @@ EXPORTS = (
     "stx_debug_planes", "stx_synth_device", "stx_device_alloc", "stx_device_free", "stx_pinned_alloc",
     "stx_pinned_free", "stx_memcpy_d2h", "stx_memcpy_h2d", "stx_set_chunk_frames", "stx_set_concurrency", "stx_set_timing", "stx_set_canny_mode",
     "stx_get_timing", "stx_preprocess_frames", "stx_preprocess_batch_device",
-    "stx_analyze_extended_frames", "stx_analyze_extended_batch_device",
+    "stx_analyze_extended_frames", "stx_analyze_extended_batch_device", "stx_submit_extended_batch_device",
+    "stx_synth_device_async",
 )
 
 
@@ -140,6 +141,7 @@ def load() -> C.CDLL:
     L.stx_debug_planes.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int64, C.POINTER(StxParams), u8p, u8p, u8p]
     L.stx_synth_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                    C.c_int]
+    L.stx_synth_device_async.argtypes = L.stx_synth_device.argtypes
     L.stx_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.stx_device_free.argtypes = [C.c_void_p, C.c_void_p]
     L.stx_pinned_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -157,5 +159,6 @@ def load() -> C.CDLL:
                                               C.c_int, C.c_int, C.c_void_p]
     L.stx_analyze_extended_frames.argtypes = L.stx_analyze_frames.argtypes + [C.POINTER(StxExtended)]
     L.stx_analyze_extended_batch_device.argtypes = L.stx_analyze_batch.argtypes + [C.POINTER(StxExtended)]
+    L.stx_submit_extended_batch_device.argtypes = L.stx_analyze_extended_batch_device.argtypes + [C.POINTER(C.c_int)]
     _lib = L
     return L

@@ -6,7 +6,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -60,6 +62,17 @@ constexpr size_t NA_TW64_H = NA_TW64_W + FFT_TABLE_MAX * sizeof(double2);
 constexpr size_t NA_BUFFERS = NA_TW64_H + FFT_TABLE_MAX * sizeof(double2);
 constexpr int NA_MAX_CHUNK = 64;  // frames per pass over the scratch array (the pinned result staging holds this many)
 
+// What this process knows about each GPU's copy of the scratch array.  The array belongs to the GPU, not to a context:
+// the lengths of the twiddle tables it holds are recorded here, where every context of that GPU sees them, and `busy`
+// turns a second allocation-free call that would overlap the first into an error instead of a race.
+constexpr int NA_MAX_DEVICES = 64;
+struct NaDevice {
+    std::mutex m;
+    bool busy = false;
+    int tw_n[4] = {0, 0, 0, 0};  // lengths of the tables currently in the array (0: none)
+};
+static NaDevice g_na_device[NA_MAX_DEVICES];
+
 // Everything derived from (frame size, parameters) that the kernels of one call need.
 struct Prepared {
     stx_params p;
@@ -83,6 +96,7 @@ struct Slot {
     hipEvent_t gray_ready = nullptr, fft_done = nullptr, stencil_done = nullptr;
     bool busy = false;      // an asynchronous submission occupies this slot
     stx_metrics* async_out = nullptr;
+    stx_extended* async_ext = nullptr;
     Prepared async_pr;
     int passes = 0;  // hysteresis passes queued so far
     bool raw = false;  // the stencil pass left raw threshold maps: flood, suppression on the flooded set, flood again
@@ -115,8 +129,9 @@ struct stx_ctx {
     // stx_analyze_batch_device_noalloc
     uint8_t* na_base = nullptr;        // device address of this GPU's copy of the scratch array
     Slot na;                           // its buffers point into the scratch array
-    void* na_stage = nullptr;          // pinned host staging for table uploads (FFT_TABLE_MAX double2, then as many float2)
-    int na_tw_n[4] = {0, 0, 0, 0};     // lengths of the tables currently in the scratch array
+    // pinned host staging for table uploads: FFT_TABLE_MAX double2, then as many float2, then the 2 * STX_MAX_DIM
+    // double2 a chirp-z table is built in
+    void* na_stage = nullptr;
     int tie_ncls = 0;
     double tie_key[4] = {0, 0, 0, 0};  // the offsets the tie tables were built for
     std::map<int, float2*> twiddles;
@@ -136,6 +151,7 @@ struct stx_ctx {
     stx_timing tacc;
     std::vector<hipEvent_t> event_pool;
     std::vector<TimedSpan> spans_kept;
+    std::vector<TimedSpan> synth_spans;  // timing spans of stx_synth_device_async launches not collected yet
 };
 
 namespace {
@@ -803,12 +819,25 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
     return STX_OK;
 }
 
-// Waits for an event by polling first: a chunk takes a millisecond or two, and the wake-up of a sleeping wait costs
-// tens of microseconds that the next call's first kernel then starts late by.
+// Waits for an event by polling first, for a bounded time: a call on a few frames is over in a fraction of a
+// millisecond, and the wake-up of a sleeping wait costs tens of microseconds that the next call's first kernel then
+// starts late by.  Longer waits (a clip takes a millisecond or more) go to sleep, so that a rank that waits for its
+// GPU leaves its core to the process that decodes the next frames.  SIFT_TEXTURE_SPIN_US sets the polling time.
+int g_spin_us = -1;
 hipError_t wait_event(hipEvent_t ev) {
-    for (int i = 0; i < 200000; ++i) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
+    if (g_spin_us < 0) {
+        const char* e = getenv("SIFT_TEXTURE_SPIN_US");
+        const long v = e ? strtol(e, nullptr, 10) : 150;
+        g_spin_us = (int)std::min<long>(std::max<long>(v, 0), 1000000);
+    }
+    if (g_spin_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(g_spin_us);
+        do {
+            for (int i = 0; i < 16; ++i) {
+                const hipError_t e = hipEventQuery(ev);
+                if (e != hipErrorNotReady) return e;
+            }
+        } while (std::chrono::steady_clock::now() < until);
     }
     return hipEventSynchronize(ev);
 }
@@ -989,7 +1018,8 @@ int stx_create(int device_id, stx_ctx** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->na.changed_host, sizeof(unsigned int) * 16, hipHostMallocDefault);
     if (e == hipSuccess) {
         *c->na.changed_host = 0;
-        e = hipHostMalloc(&c->na_stage, (sizeof(double2) + sizeof(float2)) * FFT_TABLE_MAX, hipHostMallocDefault);
+        e = hipHostMalloc(&c->na_stage, (sizeof(double2) + sizeof(float2)) * FFT_TABLE_MAX + sizeof(double2) * 2 * STX_MAX_DIM,
+                          hipHostMallocDefault);
     }
     if (e == hipSuccess) { step = "hipEventCreate"; e = hipEventCreateWithFlags(&c->na.done, hipEventDisableTiming); }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->na.gray_ready, INNER_EVENT);
@@ -1057,6 +1087,7 @@ int stx_destroy(stx_ctx* c) {
     for (auto& kv : c->twiddles64) (void)hipFree(kv.second);
     if (c->prep_out.p) (void)hipFree(c->prep_out.p);
     for (auto& kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto& t : c->synth_spans) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
@@ -1092,13 +1123,17 @@ namespace {
 // the scratch array; uploaded through the pinned staging only when the length changes.
 int na_twiddles(stx_ctx* c, int which, const FftPlan& plan) {
     const int n = plan.n;
-    if (c->na_tw_n[which] == n) return STX_OK;
+    // (the caller holds this GPU's busy flag, so nobody else reads or writes the record meanwhile)
+    int* tw_n = g_na_device[c->device].tw_n;
+    if (tw_n[which] == n) return STX_OK;
     static const size_t off[4] = {NA_TW_W, NA_TW_H, NA_TW64_W, NA_TW64_H};
     const size_t entries = fft_table_entries(plan);
     size_t bytes;
     const void* src = c->na_stage;
-    // filled in double precision in the first part of the staging; the fp32 tables are narrowed into the second
-    fft_fill_table(plan, (double*)c->na_stage);
+    // filled in double precision in the first part of the staging; the fp32 tables are narrowed into the second; a
+    // chirp-z table is built in the third
+    fft_fill_table(plan, (double*)c->na_stage,
+                   (double*)((char*)c->na_stage + (sizeof(double2) + sizeof(float2)) * FFT_TABLE_MAX));
     if (which < 2) {
         const double* t = (const double*)c->na_stage;
         float2* h = (float2*)((char*)c->na_stage + sizeof(double2) * FFT_TABLE_MAX);
@@ -1108,10 +1143,10 @@ int na_twiddles(stx_ctx* c, int which, const FftPlan& plan) {
     } else {
         bytes = sizeof(double2) * entries;
     }
-    c->na_tw_n[which] = 0;
+    tw_n[which] = 0;
     HIPCHK(c, hipMemcpyAsync(c->na_base + off[which], src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging is reused by the next table
-    c->na_tw_n[which] = n;
+    tw_n[which] = n;
     return STX_OK;
 }
 
@@ -1158,12 +1193,23 @@ int stx_analyze_batch_device_noalloc(stx_ctx* c, const uint8_t* bgr_dev, int n_f
     if (rc != STX_OK) return rc;
     if (!(pr.p.lbp_points == 8 && pr.p.lbp_radius == 1.0))
         return fail(c, STX_ERR_UNSUPPORTED, "the allocation-free entry point computes LBP at (P=8, R=1) only");
+    if (c->device >= NA_MAX_DEVICES) return fail(c, STX_ERR_UNSUPPORTED, "device id beyond the allocation-free entry point's table");
+    // one call at a time per GPU: every context of this GPU works in the same scratch array
+    NaDevice& nd = g_na_device[c->device];
+    {
+        std::lock_guard<std::mutex> lk(nd.m);
+        if (nd.busy)
+            return fail(c, STX_ERR_INVALID, "another allocation-free call is running on this GPU (its contexts share one scratch array)");
+        nd.busy = true;
+    }
     // the fp64 workspace of spec64 / scratch64 / part64 may belong to the allocating entry points: park it
     DevBuf keep[3] = {c->spec64, c->scratch64, c->part64};
     auto restore = [&]() {
         if (!keep[0].fixed) c->spec64 = keep[0]; else c->spec64 = DevBuf();
         if (!keep[1].fixed) c->scratch64 = keep[1]; else c->scratch64 = DevBuf();
         if (!keep[2].fixed) c->part64 = keep[2]; else c->part64 = DevBuf();
+        std::lock_guard<std::mutex> lk(nd.m);
+        nd.busy = false;
     };
     int chunk = std::min(n_frames, NA_MAX_CHUNK);
     while (chunk >= 1 && na_carve(c, pr, chunk) == 0) chunk = chunk > 8 ? chunk - chunk / 8 : chunk - 1;
@@ -1212,10 +1258,11 @@ int stx_max_async_frames(stx_ctx* c, int h, int w) {
     return pick_chunk(c, g, 1 << 30);
 }
 
-int stx_submit_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
-                            int64_t frame_stride, const stx_params* params, stx_metrics* out, int* ticket) {
+static int submit_common(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                         int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext, bool want_ext,
+                         int* ticket) {
     if (!c) return STX_ERR_INVALID;
-    if (!ticket || !bgr_dev || !out || n_frames < 1) return fail(c, STX_ERR_INVALID, "bad argument");
+    if (!ticket || !bgr_dev || !out || n_frames < 1 || (want_ext && !ext)) return fail(c, STX_ERR_INVALID, "bad argument");
     if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (int64_t)(h - 1) + 3 * (int64_t)w)
         return fail(c, STX_ERR_INVALID, "strides smaller than the frame");
     int si = -1;
@@ -1223,8 +1270,10 @@ int stx_submit_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, in
         if (!c->slot[i].busy) { si = i; break; }
     if (si < 0) return fail(c, STX_ERR_INVALID, "too many submissions in flight: call stx_wait first");
     Slot& sl = c->slot[si];
+    sl.async_pr = Prepared();
     int rc = prepare(c, h, w, params, &sl.async_pr);
     if (rc != STX_OK) return rc;
+    if (want_ext && (rc = prepare_extended(c, &sl.async_pr)) != STX_OK) return rc;
     if (n_frames > pick_chunk(c, sl.async_pr.g, 1 << 30))
         return fail(c, STX_ERR_UNSUPPORTED, "n_frames exceeds stx_max_async_frames for this frame size");
     ChunkOpts o;
@@ -1232,17 +1281,30 @@ int stx_submit_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, in
     if (rc != STX_OK) { sync_all(c); return rc; }
     sl.busy = true;
     sl.async_out = out;
+    sl.async_ext = want_ext ? ext : nullptr;
     *ticket = si;
     return STX_OK;
+}
+
+int stx_submit_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                            int64_t frame_stride, const stx_params* params, stx_metrics* out, int* ticket) {
+    return submit_common(c, bgr_dev, n_frames, h, w, row_stride, frame_stride, params, out, nullptr, false, ticket);
+}
+
+int stx_submit_extended_batch_device(stx_ctx* c, const uint8_t* bgr_dev, int n_frames, int h, int w, int64_t row_stride,
+                                     int64_t frame_stride, const stx_params* params, stx_metrics* out, stx_extended* ext,
+                                     int* ticket) {
+    return submit_common(c, bgr_dev, n_frames, h, w, row_stride, frame_stride, params, out, ext, true, ticket);
 }
 
 int stx_wait(stx_ctx* c, int ticket) {
     if (!c) return STX_ERR_INVALID;
     if (ticket < 0 || ticket >= N_SLOTS || !c->slot[ticket].busy) return fail(c, STX_ERR_INVALID, "unknown ticket");
     Slot& sl = c->slot[ticket];
-    const int rc = finish_chunk(c, sl, sl.async_pr, sl.async_out);
+    const int rc = finish_chunk(c, sl, sl.async_pr, sl.async_out, sl.async_ext);
     sl.busy = false;
     sl.async_out = nullptr;
+    sl.async_ext = nullptr;
     if (rc != STX_OK) sync_all(c);
     return rc;
 }
@@ -1495,6 +1557,25 @@ int stx_synth_device(stx_ctx* c, uint8_t* bgr_dev, int kind, uint64_t seed, uint
     return STX_OK;
 }
 
+int stx_synth_device_async(stx_ctx* c, uint8_t* bgr_dev, int kind, uint64_t seed, uint32_t video, uint32_t frame0,
+                           int n_frames, int h, int w) {
+    if (!c) return STX_ERR_INVALID;
+    if (!bgr_dev || n_frames < 0 || h < 1 || w < 1 || h > 8192 || w > 8192 || kind < 0 || kind > 5 ||
+        (uint64_t)frame0 + (uint64_t)n_frames > 1024 || video >= (1u << 28) || n_frames > 65535)
+        return fail(c, STX_ERR_INVALID, "synthetic generator limits: h,w<=8192, frame<1024, video<2^28");
+    if (n_frames == 0) return STX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // the stream every analysis call queues its first work on (copies, clears, a separate gray pass), and whose
+    // progress the stencil pass waits for: a call that follows reads finished frames, and until then the generator
+    // runs beside whatever the device is busy with
+    hipStream_t st = c->concurrent_fft ? c->stream_pre : c->stream;
+    Span sp(c, &c->synth_spans, STX_K_SYNTH, 1, st);
+    launch_synth(st, bgr_dev, kind, seed, video, frame0, n_frames, h, w);
+    sp.end();
+    HIPCHK(c, hipGetLastError());
+    return STX_OK;
+}
+
 int stx_device_alloc(stx_ctx* c, uint64_t bytes, void** out) {
     if (!c || !out) return STX_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1560,6 +1641,10 @@ int stx_set_timing(stx_ctx* c, int enabled) {
 }
 int stx_get_timing(stx_ctx* c, stx_timing* out, int reset) {
     if (!c || !out) return STX_ERR_INVALID;
+    if (!c->synth_spans.empty()) {
+        HIPCHK(c, hipEventSynchronize(c->synth_spans.back().e1));
+        collect_spans(c, c->synth_spans);
+    }
     *out = c->tacc;
     out->fft64_frames = c->fft64_frames;
     if (reset) {

@@ -183,7 +183,7 @@ static void chirp_at(long long k, int n, double* re, double* im) {
     *im = sin(a);
 }
 
-void fft_fill_table(const FftPlan& p, double* out) {
+void fft_fill_table(const FftPlan& p, double* out, double* work) {
     const int n = p.n;
     if (!p.bz_m) {
         for (int k = 0; k < n; ++k) {
@@ -205,7 +205,13 @@ void fft_fill_table(const FftPlan& p, double* out) {
     }
     // the convolution kernel conj(c[j]) at j and m-j, transformed (decimation in frequency, as on the device, so the
     // result is already in bit-reversed order) and divided by m
-    std::vector<double> b(2 * (size_t)m, 0.0);
+    std::vector<double> own;
+    if (!work) {
+        own.resize(2 * (size_t)m);
+        work = own.data();
+    }
+    double* b = work;
+    for (size_t j = 0; j < 2 * (size_t)m; ++j) b[j] = 0.0;
     for (int j = 0; j < n; ++j) {
         double re, im;
         chirp_at(j, n, &re, &im);

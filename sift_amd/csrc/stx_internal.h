@@ -76,8 +76,9 @@ constexpr int FFT_BLUESTEIN_MIN_PRIME = 256;
 // Entries of the table a plan's kernels read: n twiddles exp(-2 pi i k / n), or the three chirp-z tables.
 inline size_t fft_table_entries(const FftPlan& p) { return p.bz_m ? (size_t)p.n + (size_t)p.bz_m / 2 + (size_t)p.bz_m : (size_t)p.n; }
 constexpr size_t FFT_TABLE_MAX = (size_t)STX_MAX_DIM + (size_t)STX_MAX_DIM + 2 * (size_t)STX_MAX_DIM;  // n <= STX_MAX_DIM, m <= 2 STX_MAX_DIM
-// Fills a plan's table in double precision (re, im interleaved).
-void fft_fill_table(const FftPlan& p, double* out);
+// Fills a plan's table in double precision (re, im interleaved).  work: room for 2 * bz_m doubles where a chirp-z
+// table is built, or nullptr to take it from the heap.
+void fft_fill_table(const FftPlan& p, double* out, double* work = nullptr);
 
 // Partial sums of one spectrum column (weighted twice where the column stands for its mirror image too).
 // l = ln(|F|+1).  t1, t2 cover only the bins with |F| < the `small` threshold of the launch: those are the bins

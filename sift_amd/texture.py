@@ -122,6 +122,16 @@ class TextureContext:
         self._check(rc, "stx_submit_batch_device")
         return t.value
 
+    def submit_device_extended(self, dev_ptr: int, n: int, h: int, w: int, out, ext,
+                               params: Optional[StxParams] = None) -> int:
+        """submit_device plus one StxExtended record per frame in `ext`."""
+        t = C.c_int(-1)
+        rc = self.lib.stx_submit_extended_batch_device(self.handle, dev_ptr, n, h, w, 3 * w, 3 * w * h,
+                                                       C.byref(params) if params is not None else None, out, ext,
+                                                       C.byref(t))
+        self._check(rc, "stx_submit_extended_batch_device")
+        return t.value
+
     def wait(self, ticket: int):
         self._check(self.lib.stx_wait(self.handle, ticket), "stx_wait")
 
@@ -171,6 +181,11 @@ class TextureContext:
 
     def synth_device(self, dev_ptr: int, kind: int, seed: int, video: int, frame0: int, n: int, h: int, w: int):
         self._check(self.lib.stx_synth_device(self.handle, dev_ptr, kind, seed, video, frame0, n, h, w), "stx_synth_device")
+
+    def synth_device_async(self, dev_ptr: int, kind: int, seed: int, video: int, frame0: int, n: int, h: int, w: int):
+        """synth_device without the wait: ordered before this context's later analysis calls."""
+        self._check(self.lib.stx_synth_device_async(self.handle, dev_ptr, kind, seed, video, frame0, n, h, w),
+                    "stx_synth_device_async")
 
     def device_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -25,13 +25,24 @@ def _noalloc(ctx, dev, n, h, w, params=None):
 
 
 def _same(a, b, n):
+    """Both entry points run the same kernels on the same frames and sum in a fixed order: every field is equal,
+    floats included."""
     for i in range(n):
         assert list(a[i].lbp_hist[:10]) == list(b[i].lbp_hist[:10]), i
         for f in INT_FIELDS:
             assert getattr(a[i], f) == getattr(b[i], f), (i, f)
         for f in FLOAT_FIELDS:
-            assert getattr(a[i], f) == pytest.approx(getattr(b[i], f), rel=1e-4, abs=1e-12), (i, f)
+            assert getattr(a[i], f) == getattr(b[i], f), (i, f)
         assert a[i].flags == b[i].flags
+    assert bytes(a) == bytes(b)
+
+
+def _free_device_bytes():
+    """Free device memory as the HIP runtime the library is linked against reports it."""
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
 
 
 def test_noalloc_matches_allocating_entry_point_twice():
@@ -51,7 +62,9 @@ def test_noalloc_matches_allocating_entry_point_twice():
                 got = _noalloc(ctx, dev, n, h, w)
                 want = ctx.analyze_device(dev, n, h, w)
                 _same(got, want, n)
+                before = _free_device_bytes()
                 again = _noalloc(ctx, dev, n, h, w)
+                assert _free_device_bytes() == before, "the allocation-free entry point changed free device memory"
                 assert bytes(again) == bytes(got)
             finally:
                 ctx.device_free(dev)
@@ -72,3 +85,78 @@ def test_noalloc_matches_allocating_entry_point_twice():
             ctx.device_free(dev)
     finally:
         ctx.close()
+
+
+def test_noalloc_contexts_of_one_gpu_share_the_tables():
+    """The twiddle tables live in the GPU's scratch array, which every context of that GPU uses: context A at one
+    size, context B at another, A again at the first size must not transform with B's tables."""
+    from sift_amd.texture import TextureContext
+    a, b = TextureContext(0), TextureContext(0)
+    try:
+        big, small = (3, 270, 480), (2, 96, 160)
+        devs = {}
+        for ctx, (n, h, w) in ((a, big), (b, small)):
+            devs[ctx] = ctx.device_alloc(n * h * w * 3)
+            ctx.synth_device(devs[ctx], KIND_ID["natural"], 0x5EED000A, 2, 0, n, h, w)
+        want_a = a.analyze_device(devs[a], *big)
+        want_b = b.analyze_device(devs[b], *small)
+        _same(_noalloc(a, devs[a], *big), want_a, big[0])
+        _same(_noalloc(b, devs[b], *small), want_b, small[0])
+        _same(_noalloc(a, devs[a], *big), want_a, big[0])
+        _same(_noalloc(b, devs[b], *small), want_b, small[0])
+    finally:
+        for ctx, d in devs.items():
+            ctx.device_free(d)
+        a.close()
+        b.close()
+
+
+def test_noalloc_overlapping_calls_on_one_gpu_are_refused_not_raced():
+    """Two threads, a context each, calling at the same time: a call either gets the GPU's scratch array to itself
+    and returns the right records, or is refused with a clear error."""
+    import threading
+    import time
+
+    from sift_amd._lib import StxError
+    from sift_amd.texture import TextureContext
+    ctxs = [TextureContext(0), TextureContext(0)]
+    shapes = [(24, 270, 480), (16, 200, 328)]
+    devs, wants = [], []
+    try:
+        for ctx, (n, h, w) in zip(ctxs, shapes):
+            d = ctx.device_alloc(n * h * w * 3)
+            devs.append(d)
+            ctx.synth_device(d, KIND_ID["natural"], 0x5EED000B, 3, 0, n, h, w)
+            wants.append(bytes(ctx.analyze_device(d, n, h, w)))
+        done, refused, wrong, errors = [0, 0], [0, 0], [0, 0], []
+
+        def work(k):
+            ctx, (n, h, w) = ctxs[k], shapes[k]
+            deadline = time.monotonic() + 60.0
+            while done[k] < 30 and time.monotonic() < deadline:
+                try:
+                    got = _noalloc(ctx, devs[k], n, h, w)
+                except StxError as e:
+                    if "another allocation-free call" in str(e):
+                        refused[k] += 1
+                        time.sleep(0.0002)
+                    else:
+                        errors.append(str(e))
+                    continue
+                done[k] += 1
+                if bytes(got) != wants[k]:
+                    wrong[k] += 1
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert wrong == [0, 0], (wrong, done, refused)
+        assert done == [30, 30], (done, refused)
+    finally:
+        for ctx, d in zip(ctxs, devs):
+            ctx.device_free(d)
+        for ctx in ctxs:
+            ctx.close()
