@@ -491,10 +491,10 @@ int hyst_passes(stx_ctx* c, Slot& sl, int n, const Geom& g, hipStream_t st = nul
         // (after the suppression on a flooded set few tiles are left to grow: two grid-wide passes, then per-frame ones)
         if (sl.passes < (sl.raw ? RAW_SECOND_GRID : HYST_GRID_PASSES))
             launch_hyst_pass(st, (unsigned long long*)sl.strong.p, cand, sl.F, g,
-                             (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
+                             (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p, sl.raw);
         else
             launch_hyst_finish(st, (unsigned long long*)sl.strong.p, cand, sl.F, g,
-                               (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p);
+                               (unsigned int*)sl.changed.p, sl.passes, (uint32_t*)sl.tiles.p, (uint8_t*)sl.tflag.p, sl.raw);
     }
     sp.end();
     return STX_OK;
@@ -530,7 +530,9 @@ void chunk_sizes(const Prepared& pr, int F, size_t (&n)[CB_COUNT], bool raw = fa
     n[CB_SPEC] = (size_t)F * pr.lay.nkb * g.fh * pr.lay.cbw * sizeof(float2);
     n[CB_PART] = (size_t)F * pr.lay.parts_per_frame * sizeof(FftPart);
     n[CB_TILES] = (size_t)F * g.bm_tiles * g.bm_words * sizeof(uint32_t);
-    n[CB_TFLAG] = (size_t)2 * F * g.bm_tiles * g.bm_words;
+    // two flag halves (pass parities), a third part for the validity bytes of a raw chunk's second candidate map;
+    // four spare bytes: the second half is cleared in whole words
+    n[CB_TFLAG] = (size_t)3 * F * g.bm_tiles * g.bm_words + 4;
     n[CB_SPART] = (size_t)F * g.tiles_x * g.tiles_y * 16 * sizeof(uint32_t);
     n[CB_ACC] = (size_t)F * sizeof(FrameAcc);
     n[CB_CHANGED] = (size_t)(HYST_MAX_PASSES + RAW_WORDS) * sizeof(unsigned int);
@@ -618,17 +620,18 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
         if (spre != s) HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));
     }
-    HIPCHK(c, hipMemsetAsync(acc, 0, (size_t)F * sizeof(FrameAcc), sclr));
-    HIPCHK(c, hipMemsetAsync(sl.changed.p, 0, (size_t)HYST_FIRST_PASSES * sizeof(unsigned int), sclr));
-    if (sl.raw) {
-        HIPCHK(c, hipMemsetAsync((unsigned int*)sl.changed.p + HYST_MAX_PASSES, 0, (size_t)RAW_WORDS * sizeof(unsigned int), sclr));
-        HIPCHK(c, hipMemsetAsync(sl.nmscount.p, 0, (size_t)F * sizeof(unsigned int), sclr));
-        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)((unsigned int*)sl.changed.p + RAW_SECOND_START - 1), 1, 1, sclr));
-        HIPCHK(c, hipMemsetAsync(sl.cand2.p, 0, need[CB_CAND2], sclr));
-    }
     const bool lbp81 = (p.lbp_points == 8 && p.lbp_radius == 1.0);
     if (lbp81 && (rc = ensure_tie_tables(c, pr.off)) != STX_OK) return rc;
-    HIPCHK(c, hipMemsetAsync((uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, 0, (size_t)F * g.bm_tiles * g.bm_words, sclr));
+    {
+        unsigned int* ch = (unsigned int*)sl.changed.p;
+        const size_t half = (size_t)F * g.bm_tiles * g.bm_words;
+        // (the second flag half may start at an odd byte: cleared from the word that holds its first byte -- the bytes
+        // of the first half in that word are flags no kernel has written yet -- to the word that holds its last)
+        uint8_t* sf = (uint8_t*)sl.tflag.p + (half & ~(size_t)3);
+        launch_chunk_init(sclr, acc, F, ch, HYST_FIRST_PASSES, sl.raw ? ch + HYST_MAX_PASSES : nullptr, RAW_WORDS,
+                          sl.raw ? ch + RAW_SECOND_START - 1 : nullptr, sl.raw ? (unsigned int*)sl.nmscount.p : nullptr,
+                          sf, half + (half & 3));
+    }
     if (fused_flow) {
         HIPCHK(c, hipEventRecord(sl.gray_ready, spre));
         HIPCHK(c, hipStreamWaitEvent(s, sl.gray_ready, 0));

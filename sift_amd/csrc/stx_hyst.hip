@@ -13,6 +13,8 @@
 // iterates to its local fix-point, then the host launches further passes until a pass
 // changes nothing anywhere (stale reads of a neighbouring tile's words are harmless: the
 // map only ever grows, and the last pass re-checks every tile against final neighbours).
+#include <algorithm>
+
 #include "stx_internal.h"
 
 namespace stx {
@@ -47,9 +49,11 @@ __device__ __forceinline__ unsigned long long flood_runs(unsigned long long c, u
 // changed in the previous pass.  nlines = image width, nwords = words per line, ntiles =
 // 64-line tiles across the image.
 // returns (wave-uniform) whether the tile changed; changed may be null
+// cvalid: null, or one byte per tile: 0 = the tile's words of `cand` were never written and count as empty
 __device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
                                           int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
-                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half);
+                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half,
+                                          const uint8_t* __restrict__ cvalid);
 
 // Four waves per workgroup, each working on tiles of its own.
 constexpr int HYST_WAVES = 4;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
                                                                     int nlines, int nwords, int ntiles, int total_tiles,
                                                                     unsigned int* changed, int pass,
                                                                     uint32_t* __restrict__ tile_count, uint8_t* tflag,
-                                                                    int64_t tflag_half) {
+                                                                    int64_t tflag_half, const uint8_t* __restrict__ cvalid) {
     if (pass > 0 && changed[pass - 1] == 0) return;
     const int wave = blockIdx.x * HYST_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * HYST_WAVES;
     if (pass == 0) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half);
+                hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half, cvalid);
             }
         }
         return;
@@ -127,14 +131,15 @@ __global__ __launch_bounds__(64 * HYST_WAVES) void hyst_pass_kernel(unsigned lon
         while (todo) {
             const int l = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half);
+            hyst_tile(strong, cand, nlines, nwords, ntiles, (j0 + l) * nwaves + wave, changed, pass, tile_count, tflag, tflag_half, cvalid);
         }
     }
 }
 
 __device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ strong, const unsigned long long* __restrict__ cand,
                                           int nlines, int nwords, int ntiles, int tile_id, unsigned int* changed, int pass,
-                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half) {
+                                          uint32_t* __restrict__ tile_count, uint8_t* tflag, int64_t tflag_half,
+                                          const uint8_t* __restrict__ cvalid) {
     const int tpf = ntiles * nwords;
     const int frame = tile_id / tpf;
     const int rem = tile_id - frame * tpf;
@@ -149,7 +154,7 @@ __device__ __forceinline__ bool hyst_tile(unsigned long long* __restrict__ stron
     const bool lin = ln < nlines;
     const bool hasl = wx > 0, hasr = wx + 1 < nwords;  // previous / next word along the lines
     unsigned long long S = 0, C = 0, Lw = 0, Rw = 0;
-    if (lin) C = cb[ln];
+    if (lin && (!cvalid || cvalid[tile_id])) C = cb[ln];
     if (!__any(C != 0)) {
         // no candidate in the tile (strong pixels are candidates too): nothing here can ever change
         if (lane == 0) {
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
                                                            const unsigned long long* __restrict__ cand, int nlines,
                                                            int nwords, int ntiles, unsigned int* changed, int pass,
                                                            uint32_t* __restrict__ tile_count, uint8_t* tflag,
-                                                           int64_t tflag_half) {
+                                                           int64_t tflag_half, const uint8_t* __restrict__ cvalid) {
     if (changed[pass - 1] == 0) return;
     __shared__ int round_changed[2];
     const int frame = blockIdx.x;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 any |= hyst_tile(strong, cand, nlines, nwords, ntiles, (int)(tbase + (j0 + l) * nwaves + wave), nullptr, p, tile_count,
-                                 tflag, tflag_half);
+                                 tflag, tflag_half, cvalid);
             }
         }
         if (any && lane == 0) round_changed[round & 1] = 1;
@@ -303,8 +308,10 @@ __global__ __launch_bounds__(1024) void hyst_finish_kernel(unsigned long long* _
 // Two kernels.  nms_collect_kernel looks at the per-tile counts the flood left (64 tiles at a time, one per lane) and,
 // for every tile that holds flooded pixels, a wave (lane = pixel column, word = 64 rows) appends them to the frame's
 // list -- one atomic per tile reserves the room -- and clears the tile's words of `strong` and the tiles' flags.  nms_apply_kernel takes one list entry per
-// thread, so the work is spread evenly however the pixels cluster; a pixel that passes sets its bit in `cand2` (a map
-// the caller zeroed; and in `strong`, and sets its tile's flag) with an atomic or.  A frame whose list would overflow (the
+// thread, so the work is spread evenly however the pixels cluster; a pixel that passes sets its bit in `cand2` (and in
+// `strong`, and sets its tile's flag) with an atomic or.  Nobody clears `cand2` as a whole: the collecting kernel
+// zeroes the words of the tiles that hold flooded pixels and records in `cvalid`, a byte per tile, which tiles those
+// are; the flood that follows takes every other tile's words as empty without reading them.  A frame whose list would overflow (the
 // flooded set is larger than 4 % of the frame) raises *unsettled and the caller runs the chunk the ordinary way.
 constexpr int NMS_WAVES = 4;
 // L1 Sobel magnitude of the replicate-bordered gray image at (y, x); 0 outside the image
@@ -334,6 +341,8 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned lo
                                                                      int nwords, int ntiles, int total_tiles,
                                                                      uint32_t* __restrict__ tile_count,
                                                                      uint8_t* __restrict__ sflag,
+                                                                     unsigned long long* __restrict__ cand2,
+                                                                     uint8_t* __restrict__ cvalid,
                                                                      uint32_t* __restrict__ list, int list_cap,
                                                                      unsigned int* __restrict__ count,
                                                                      unsigned int* __restrict__ unsettled) {
@@ -349,6 +358,7 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned lo
             // the flood that follows counts from zero and starts from the flags the suppression sets
             tile_count[mine] = 0;
             sflag[mine] = 0;
+            cvalid[mine] = had != 0 ? 1 : 0;
         }
         unsigned long long todo = __ballot(had != 0);
         while (todo) {
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(64 * NMS_WAVES) void nms_collect_kernel(unsigned lo
             const bool lin = ln < nlines;
             const int64_t idx = ((int64_t)frame * nwords + wx) * nlines + ln;
             const unsigned long long R = lin ? strong[idx] : 0ull;
+            if (lin) cand2[idx] = 0ull;
             const uint32_t cnt = (uint32_t)__popcll(R);
             if (!__any(cnt != 0)) continue;
             if (R != 0) strong[idx] = 0ull;
@@ -554,21 +565,22 @@ __global__ __launch_bounds__(256) void edges_expand_kernel(const unsigned long l
 }
 
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag, bool cand_sparse) {
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     const int total = (int)half;
     int grid = (total + HYST_WAVES - 1) / HYST_WAVES;
     const int cap = pass <= 1 ? HYST_MAX_GRID : HYST_LATER_GRID;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(hyst_pass_kernel, dim3(grid), dim3(64 * HYST_WAVES), 0, s, strong,
-                       cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half);
+                       cand, g.W, g.bm_words, g.bm_tiles, total, changed, pass, tile_count, tflag, half,
+                       cand_sparse ? (const uint8_t*)(tflag + 2 * half) : nullptr);
 }
 
 void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                        const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag) {
+                        const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag, bool cand_sparse) {
     const int64_t half = (int64_t)n_frames * g.bm_tiles * g.bm_words;
     hipLaunchKernelGGL(hyst_finish_kernel, dim3(n_frames), dim3(1024), 0, s, strong, cand, g.W, g.bm_words, g.bm_tiles,
-                       changed, pass, tile_count, tflag, half);
+                       changed, pass, tile_count, tflag, half, cand_sparse ? (const uint8_t*)(tflag + 2 * half) : nullptr);
 }
 
 int nms_list_cap(const Geom& g) {
@@ -587,12 +599,47 @@ void launch_nms_sparse(hipStream_t s, unsigned long long* strong, unsigned long 
     int grid = (total + 8 * NMS_WAVES - 1) / (8 * NMS_WAVES);
     if (grid > HYST_MAX_GRID) grid = HYST_MAX_GRID;
     hipLaunchKernelGGL(nms_collect_kernel, dim3(grid), dim3(64 * NMS_WAVES), 0, s, strong, g.W, g.bm_words, g.bm_tiles, total,
-                       tile_count, tflag + half, list, cap, count, unsettled);
+                       tile_count, tflag + half, cand2, tflag + 2 * half, list, cap, count, unsettled);
     // magnitudes are at most 2040: thresholds outside [-1, 4095] behave like the nearest bound (as in the stencil pass)
     const int lo = low < -1 ? -1 : (low > 4095 ? 4095 : low), hi = high < -1 ? -1 : (high > 4095 ? 4095 : high);
     const int bpf = (cap + 255) / 256;
     hipLaunchKernelGGL(nms_apply_kernel, dim3((unsigned)(bpf < 32 ? bpf : 32), (unsigned)n_frames), dim3(256), 0, s, strong, cand2,
                        gray, g.gpitch, g.grows, g.H, g.W, g.bm_words, g.bm_tiles, lo, hi, tflag + half, list, cap, count, reached_total);
+}
+
+// Everything a chunk needs cleared before its first kernel, in one launch: the per-frame accumulators, the pass
+// counters of the hysteresis (and, for a chunk whose stencil pass leaves raw threshold maps, those of the flood of the
+// raw maps, the per-frame list lengths, and the preset "the pass before changed something" of the flood after the
+// suppression), and the flag half in which the stencil pass marks the tiles that hold a strong pixel.
+__global__ __launch_bounds__(256) void chunk_init_kernel(uint32_t* __restrict__ acc_words, int n_acc_words,
+                                                         unsigned int* __restrict__ changed, int n_changed,
+                                                         unsigned int* __restrict__ raw_changed, int n_raw_changed,
+                                                         unsigned int* __restrict__ preset_one,
+                                                         unsigned int* __restrict__ nmscount, int n_frames,
+                                                         uint32_t* __restrict__ sflag_words, int n_sflag_words) {
+    const int stride = gridDim.x * 256;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    for (int i = t; i < n_acc_words; i += stride) acc_words[i] = 0u;
+    for (int i = t; i < n_sflag_words; i += stride) sflag_words[i] = 0u;
+    if (t < n_changed) changed[t] = 0u;
+    if (raw_changed) {
+        if (t < n_raw_changed) raw_changed[t] = 0u;
+        for (int i = t; i < n_frames; i += stride) nmscount[i] = 0u;
+        if (t == 0) *preset_one = 1u;
+    }
+}
+
+void launch_chunk_init(hipStream_t s, FrameAcc* acc, int n_frames, unsigned int* changed, int n_changed,
+                       unsigned int* raw_changed, int n_raw_changed, unsigned int* preset_one, unsigned int* nmscount,
+                       uint8_t* sflag, size_t sflag_bytes) {
+    static_assert(sizeof(FrameAcc) % 4 == 0, "cleared as 32-bit words");
+    const int n_acc_words = (int)((size_t)n_frames * sizeof(FrameAcc) / 4);
+    const int n_sflag_words = (int)((sflag_bytes + 3) / 4);  // (the buffer's size is rounded up to whole words)
+    int grid = (std::max(n_acc_words, n_sflag_words) + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    hipLaunchKernelGGL(chunk_init_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<uint32_t*>(acc), n_acc_words, changed,
+                       n_changed, raw_changed, n_raw_changed, preset_one, nmscount, n_frames,
+                       reinterpret_cast<uint32_t*>(sflag), n_sflag_words);
 }
 
 void launch_frame_reduce(hipStream_t s, const uint32_t* spart, bool lbp_from_tiles, const uint32_t* tile_count,

@@ -126,15 +126,25 @@ void launch_extended(hipStream_t s, const uint8_t* gray, int n_frames, const Geo
 
 // One hysteresis pass over every 64x64 tile of every frame; pass p exits at once when pass p-1
 // changed nothing.  changed[] must be zeroed before pass 0.  tile_count: [frame][bm_tiles][bm_words].
+// cand_sparse: `cand` is the map launch_nms_sparse filled -- only the tiles its validity bytes (the third part of
+// tflag) name were written, every other tile counts as empty.
 void launch_hyst_pass(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag,
+                      bool cand_sparse = false);
 // Pass number `pass` >= 1 as one workgroup per frame that repeats the pass until the frame is done (or a
 // round limit is reached: then changed[pass] is set and the caller queues it again).
 void launch_hyst_finish(hipStream_t s, unsigned long long* strong, const unsigned long long* cand, int n_frames,
-                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag);
+                      const Geom& g, unsigned int* changed, int pass, uint32_t* tile_count, uint8_t* tflag,
+                      bool cand_sparse = false);
+// One launch for all the clears a chunk needs before its first kernel (see chunk_init_kernel).  raw_changed / preset_one /
+// nmscount may be null together (a chunk without the flood of raw maps); sflag_bytes is rounded up to whole words.
+void launch_chunk_init(hipStream_t s, FrameAcc* acc, int n_frames, unsigned int* changed, int n_changed,
+                       unsigned int* raw_changed, int n_raw_changed, unsigned int* preset_one, unsigned int* nmscount,
+                       uint8_t* sflag, size_t sflag_bytes);
 // After a flood of RAW threshold maps (`strong` = the flooded set, tile_count = its size per tile as the flood left it):
 // non-maximum suppression of the pixels in the set from the gray plane.  Leaves the suppressed candidates in `cand2`
-// (zeroed by the caller), "tile holds a strong pixel" in the second half of tflag (what hysteresis pass 0 reads, and
+// (written only in the tiles the flood reached; one byte per tile in the third part of tflag, which must have room for
+// it, says which those are), "tile holds a strong pixel" in the second half of tflag (what hysteresis pass 0 reads, and
 // what launch_hyst_finish reads as the flags of an odd pass before it), the suppressed strong pixels in `strong`, zeros
 // in tile_count, and adds the size of the set to *reached_total.
 // list: [n_frames][nms_list_cap(g)] entries, count: [n_frames], zeroed by the caller; *unsettled is set when a frame's

@@ -2,7 +2,7 @@
 # Everything profiles/ holds for one round, run on the GPU box from the repository root:
 #   tools/profile_round.sh <tag>        -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,6 +14,8 @@ for c in crops256 4k_multiradius 720p; do
   step bench $c
   timeout -k 10 300 python3 bench.py --config $c --steps 20 --warmup 2 --cpu-seconds 8 > $OUT/bench_$c.json 2> $OUT/bench_$c.err || exit 1
 done
+step bench clips10k
+timeout -k 10 300 python3 bench.py --config clips10k --warmup 2 > $OUT/bench_clips10k.json 2> $OUT/bench_clips10k.err || exit 1
 step host-fed
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --host-fed > $OUT/bench_hostfed.json 2> $OUT/bench_hostfed.err || exit 1
 step latency
