@@ -663,9 +663,8 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
             launch_extended(s, (const uint8_t*)sl.gray.p, F, g, p.canny_high, (unsigned long long*)sl.xpart.p, acc);
             sp.end();
         }
-        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 4, s);
-        const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, 16, pr.off2, (uint32_t*)sl.lpart.p, acc, nullptr, 1) &&
-                        launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, 24, pr.off3, (uint32_t*)sl.lpart.p, acc, nullptr, 2);
+        Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 3, s);
+        const bool ok = launch_lbp_rings(s, (const uint8_t*)sl.gray.p, F, g, pr.off2, pr.off3, (uint32_t*)sl.lpart.p, acc);
         sp.end();
         if (!ok) return fail(c, STX_ERR_UNSUPPORTED, "lbp_radius too large for one LDS tile");
     }

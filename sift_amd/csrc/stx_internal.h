@@ -119,6 +119,10 @@ void build_tie_tables(const LbpOffsets& off, std::vector<uint8_t>* blob, int* n_
 size_t lbp_generic_part_bytes(const Geom& g, int n_frames);
 bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
                         uint32_t* part, FrameAcc* acc, uint8_t* codes_out, int hist_slot = 0);
+// (P=16, R=2) and (P=24, R=3) in one launch from one tile, into acc[].lbp_hist2 / lbp_hist3 (two launches of the kernel
+// above where the offsets are not those of the compiled cell tables).
+bool launch_lbp_rings(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const LbpOffsets& off16,
+                      const LbpOffsets& off24, uint32_t* part, FrameAcc* acc);
 // Sobel-magnitude and 8x8 blockiness sums per frame into acc[] (stx_extended.hip).
 size_t extended_part_bytes(const Geom& g, int n_frames);
 void launch_extended(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int high, unsigned long long* part,

@@ -73,27 +73,16 @@ struct Ring {
 
 constexpr int GL_QUEUE = 256;  // undecided pixels a wave can queue per strip of GL_ROWS rows
 
-template <int PT, bool RING>
-__global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
-    extern __shared__ uint32_t gl_tile[];  // (GL_TILE + 2*halo) rows of lpitch pairs
-    // Sixteen copies of the histogram, 33 words apart (a copy per bank offset): neighbouring pixels mostly
-    // fall into the same bin, and 64 lanes adding to one LDS word would be served one after the other.
-    __shared__ uint32_t hist[GL_COPIES * GL_HSTRIDE];
-    __shared__ double offs[2][24];
-    // undecided pixels of each wave's strip: .x = sign bits | row << 24, .y = undecided samples | lane << 24
-    __shared__ uint2 queue[4][GL_QUEUE];
-    const int frame = blockIdx.z;
-    const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
-    const int tid = threadIdx.x;
-    const int halo = RING ? Ring<PT>::HALO : a.halo, lpitch = RING ? Ring<PT>::LPITCH : a.lpitch;
+// Fills the LDS tile of packed pairs (pixel, right neighbour) for the GL_TILE x GL_TILE pixels at (x0, y0) and `halo`
+// pixels around them; pixels outside the image are zero.  gp: the frame's padded gray plane.
+__device__ __forceinline__ void load_pair_tile(uint32_t* gl_tile, const uint8_t* gp, int gpitch, int H, int W, int x0, int y0,
+                                               int halo, int lpitch, int tid) {
     const int trows = GL_TILE + 2 * halo;
-
-    const uint8_t* gp = a.gray + (int64_t)frame * a.grows * a.gpitch;
     // Tiles that lie inside the image with their halo (and one more column for the last pair) need no zero fill:
     // a thread takes eight entries of a row from twelve bytes (three unaligned 32-bit loads), every load of the
     // tile is issued before the first LDS store, and there is no division.  (The general loop below waits for
     // two dependent byte loads per entry, nineteen times in a row per thread.)
-    const bool inside = x0 - halo >= 0 && y0 - halo >= 0 && x0 + GL_TILE + halo + 1 <= a.W && y0 + GL_TILE + halo <= a.H;
+    const bool inside = x0 - halo >= 0 && y0 - halo >= 0 && x0 + GL_TILE + halo + 1 <= W && y0 + GL_TILE + halo <= H;
     if (inside) {
         constexpr int SEG = 8;
         const int segs = (GL_TILE + 2 * halo + SEG - 1) / SEG;  // per row; the last one may run past the row's entries
@@ -108,7 +97,7 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
                 rr[k] = t / segs;
                 ss[k] = t - rr[k] * segs;
                 if (t < tasks) {
-                    const uint8_t* src = gp + (int64_t)(y0 - halo + rr[k] + GRAY_YOFF) * a.gpitch + GRAY_XOFF + x0 - halo + SEG * ss[k];
+                    const uint8_t* src = gp + (int64_t)(y0 - halo + rr[k] + GRAY_YOFF) * gpitch + GRAY_XOFF + x0 - halo + SEG * ss[k];
                     __builtin_memcpy(&w[k][0], src, 4);
                     __builtin_memcpy(&w[k][1], src + 4, 4);
                     __builtin_memcpy(&w[k][2], src + 8, 4);
@@ -135,13 +124,29 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
         const int r = i / lpitch, cidx = i - r * lpitch;
         const int gy = y0 - halo + r, gx = x0 - halo + cidx;
         uint32_t v = 0;
-        if (gy >= 0 && gy < a.H) {
-            const uint8_t* rowp = gp + (int64_t)(gy + GRAY_YOFF) * a.gpitch + GRAY_XOFF;
-            if (gx >= 0 && gx < a.W) v = rowp[gx];
-            if (gx + 1 >= 0 && gx + 1 < a.W) v |= (uint32_t)rowp[gx + 1] << 16;
+        if (gy >= 0 && gy < H) {
+            const uint8_t* rowp = gp + (int64_t)(gy + GRAY_YOFF) * gpitch + GRAY_XOFF;
+            if (gx >= 0 && gx < W) v = rowp[gx];
+            if (gx + 1 >= 0 && gx + 1 < W) v |= (uint32_t)rowp[gx + 1] << 16;
         }
         gl_tile[i] = v;
     }
+}
+
+template <int PT, bool RING>
+__global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
+    extern __shared__ uint32_t gl_tile[];  // (GL_TILE + 2*halo) rows of lpitch pairs
+    // Sixteen copies of the histogram, 33 words apart (a copy per bank offset): neighbouring pixels mostly
+    // fall into the same bin, and 64 lanes adding to one LDS word would be served one after the other.
+    __shared__ uint32_t hist[GL_COPIES * GL_HSTRIDE];
+    __shared__ double offs[2][24];
+    // undecided pixels of each wave's strip: .x = sign bits | row << 24, .y = undecided samples | lane << 24
+    __shared__ uint2 queue[4][GL_QUEUE];
+    const int frame = blockIdx.z;
+    const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
+    const int tid = threadIdx.x;
+    const int halo = RING ? Ring<PT>::HALO : a.halo, lpitch = RING ? Ring<PT>::LPITCH : a.lpitch;
+    load_pair_tile(gl_tile, a.gray + (int64_t)frame * a.grows * a.gpitch, a.gpitch, a.H, a.W, x0, y0, halo, lpitch, tid);
     for (int i = tid; i < GL_COPIES * GL_HSTRIDE; i += 256) hist[i] = 0;
     if (tid < 24) { offs[0][tid] = a.off.rp[tid]; offs[1][tid] = a.off.cp[tid]; }
     __syncthreads();
@@ -287,6 +292,210 @@ __global__ __launch_bounds__(256) void lbp_generic_kernel(LbpGenArgs a) {
     }
 }
 
+
+// ---- (P=16, R=2) and (P=24, R=3) together: the two extra radii of the extended analysis from one tile.
+// One LDS tile with the wider halo serves both rings.  A lane owns a pixel column and marches down its strip: the
+// lower cell row of a sample at image row y is the upper cell row of the same sample at row y+1, so each blended
+// sample keeps the word it read last in a register and reads one new word per row instead of two (41 LDS reads per
+// pixel for the 32 blended and 8 on-pixel samples of the two rings and the centre, against 74 as two launches; the
+// rows are unrolled in pairs so that the two sets of registers swap roles without copies).  Decisions, margins and
+// the fp64 replay of undecided pixels are those of lbp_generic_kernel<PT, true>.
+struct LbpRingsArgs {
+    const uint8_t* gray;
+    int H, W, gpitch, grows;
+    uint32_t margin16, margin24;
+    uint32_t wtop16[16], wbot16[16], wtop24[24], wbot24[24];
+    LbpOffsets off16, off24;
+    uint32_t* part16;  // [frame][tiles][GL_BINS]
+    uint32_t* part24;
+};
+
+// cell offsets of ring PT in the tile of halo 3 (entries, relative to the entry 3 rows and 3 columns up and left of the centre)
+template <int PT>
+struct Ring3 {
+    static constexpr int HALO = 3;
+    static constexpr int LPITCH = (GL_TILE + 2 * HALO) | 1;
+    static constexpr int top(int p) { return (Ring<PT>::fr(p) + HALO) * LPITCH + Ring<PT>::fc(p) + HALO; }
+    static constexpr int bot(int p) { return top(p) + Ring<PT>::d1(p) * LPITCH; }
+};
+
+// Which blended samples of ring PT at one pixel are too close to call (sample p at bit PT-1-p), both cell rows read
+// again: t < lim as unsigned numbers is the borrow of t - lim, except where t itself has its top bit set (a sample
+// decidedly below the centre), which the pixel's sign word -- `below`, one bit per sample -- tells.
+template <int PT>
+__device__ __forceinline__ uint32_t ring_near(const uint8_t* pr, const uint32_t* wtop, const uint32_t* wbot, uint32_t init,
+                                              uint32_t lim, uint32_t below) {
+    uint32_t near = 0;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        if (Ring<PT>::d1(p) != 0) {
+            const uint32_t top = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<PT>::top(p));
+            const uint32_t bot = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<PT>::bot(p));
+            const uint32_t t = dot2(top, wtop[p], dot2(bot, wbot[p], init));
+            near = __builtin_amdgcn_alignbit(near, t - lim, 31);
+        } else {
+            near += near;
+        }
+    }
+    return near & ~below;
+}
+
+// the samples of `near` (sample p at bit P-1-p) of pixel (y, xx) in skimage's bilinear_interpolation, operation by operation
+__device__ __forceinline__ uint32_t ring_settle(const uint32_t* tile, int lpitch, int halo, int x0, int y0, int P,
+                                                const double* rp, const double* cp, uint32_t bits, uint32_t near, int y, int xx) {
+    const double c = (double)(tile[(y - y0 + halo) * lpitch + (xx - x0 + halo)] & 0xFFFFu);
+    while (near != 0) {
+        const int b = __ffs(near) - 1;
+        near &= near - 1;
+        const int p = P - 1 - b;
+        const double rf = (double)y + rp[p], cf = (double)xx + cp[p];
+        const double fr = floor(rf), fc = floor(cf);
+        const int minr = (int)fr, minc = (int)fc;
+        const int maxr = (int)ceil(rf), maxc = (int)ceil(cf);
+        const double dr = rf - fr, dc = cf - fc;
+        auto px = [&](int yy, int xq) -> double {
+            return (double)(tile[(yy - y0 + halo) * lpitch + (xq - x0 + halo)] & 0xFFFFu);
+        };
+        const double tl = px(minr, minc), tr = px(minr, maxc), bl = px(maxr, minc), br = px(maxr, maxc);
+        const double top = (1.0 - dc) * tl + dc * tr;
+        const double bottom = (1.0 - dc) * bl + dc * br;
+        const double t = (1.0 - dr) * top + dr * bottom;
+        const uint32_t bit = (t - c >= 0.0) ? 1u : 0u;
+        bits = (bits & ~(1u << b)) | (bit << b);
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void lbp_rings_kernel(LbpRingsArgs a) {
+    constexpr int HALO = Ring3<24>::HALO, LP = Ring3<24>::LPITCH, TROWS = GL_TILE + 2 * HALO;
+    __shared__ uint32_t tile[TROWS * LP];
+    __shared__ uint32_t hist16[GL_COPIES * GL_HSTRIDE], hist24[GL_COPIES * GL_HSTRIDE];
+    __shared__ double offs[4][24];  // rp16, cp16, rp24, cp24
+    // undecided pixels of each wave's strip: .x = bits of ring 16 | row << 16 | undecided in ring 16 << 30 | in ring 24
+    // << 31, .y = bits of ring 24 | lane << 24
+    __shared__ uint2 queue[4][GL_QUEUE];
+    const int frame = blockIdx.z;
+    const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
+    const int tid = threadIdx.x;
+    load_pair_tile(tile, a.gray + (int64_t)frame * a.grows * a.gpitch, a.gpitch, a.H, a.W, x0, y0, HALO, LP, tid);
+    for (int i = tid; i < GL_COPIES * GL_HSTRIDE; i += 256) { hist16[i] = 0; hist24[i] = 0; }
+    if (tid < 24) {
+        offs[0][tid] = a.off16.rp[tid]; offs[1][tid] = a.off16.cp[tid];
+        offs[2][tid] = a.off24.rp[tid]; offs[3][tid] = a.off24.cp[tid];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = x0 + lane;
+    const bool valid = x < a.W;
+    const uint32_t lim16 = 2u * a.margin16 + 1u, lim24 = 2u * a.margin24 + 1u;
+    auto count = [&](uint32_t* hist, int P, uint32_t bits) {
+        const int changes = __popc((bits ^ (bits >> 1)) & ((1u << (P - 1)) - 1u));
+        const int code = (changes <= 2) ? __popc(bits) : P + 1;
+        atomicAdd(&hist[(lane & (GL_COPIES - 1)) * GL_HSTRIDE + code], 1u);
+    };
+    // the words the blended samples read last: X holds the upper cell rows of the row about to be processed
+    uint32_t X16[16], Y16[16], X24[24], Y24[24];
+    const int ys = y0 + wv * GL_ROWS;
+    uint32_t pro = 4u * (uint32_t)(wv * GL_ROWS * LP + lane);
+    asm volatile("" : "+v"(pro));
+    const uint8_t* pr0 = reinterpret_cast<const uint8_t*>(tile) + pro;
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+        if (Ring<16>::d1(p)) X16[p] = *reinterpret_cast<const uint32_t*>(pr0 + 4 * Ring3<16>::top(p));
+#pragma unroll
+    for (int p = 0; p < 24; ++p)
+        if (Ring<24>::d1(p)) X24[p] = *reinterpret_cast<const uint32_t*>(pr0 + 4 * Ring3<24>::top(p));
+    uint32_t qn = 0;  // entries in this wave's queue (wave-uniform)
+    // one image row: T = upper cell rows (read a row ago), B = lower cell rows (read now, next row's upper ones)
+    auto row = [&](int i, uint32_t (&T16)[16], uint32_t (&B16)[16], uint32_t (&T24)[24], uint32_t (&B24)[24]) {
+        const uint8_t* pr = pr0 + 4 * i * LP;
+        const uint32_t c = *reinterpret_cast<const uint32_t*>(pr + 4 * (HALO * LP + HALO)) & 0xFFFFu;
+        const uint32_t init16 = a.margin16 - (c << 16), init24 = a.margin24 - (c << 16);
+        uint32_t s16 = 0, s24 = 0, tmin16 = 0xFFFFFFFFu, tmin24 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (Ring<16>::d1(p) == 0) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<16>::top(p));
+                s16 = __builtin_amdgcn_alignbit(s16, (v << 16) + init16, 31);
+            } else {
+                B16[p] = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<16>::bot(p));
+                const uint32_t t = dot2(T16[p], a.wtop16[p], dot2(B16[p], a.wbot16[p], init16));
+                s16 = __builtin_amdgcn_alignbit(s16, t, 31);
+                tmin16 = tmin16 < t ? tmin16 : t;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 24; ++p) {
+            if (Ring<24>::d1(p) == 0) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<24>::top(p));
+                s24 = __builtin_amdgcn_alignbit(s24, (v << 16) + init24, 31);
+            } else {
+                B24[p] = *reinterpret_cast<const uint32_t*>(pr + 4 * Ring3<24>::bot(p));
+                const uint32_t t = dot2(T24[p], a.wtop24[p], dot2(B24[p], a.wbot24[p], init24));
+                s24 = __builtin_amdgcn_alignbit(s24, t, 31);
+                tmin24 = tmin24 < t ? tmin24 : t;
+            }
+        }
+        const uint32_t bits16 = ~s16 & 0xFFFFu, bits24 = ~s24 & 0xFFFFFFu;  // LBP bit = sample >= centre
+        const bool und16 = valid && tmin16 < lim16, und24 = valid && tmin24 < lim24;
+        if (valid && !und16) count(hist16, 16, bits16);
+        if (valid && !und24) count(hist24, 24, bits24);
+        const bool und = und16 || und24;
+        const unsigned long long um = __ballot(und);
+        if (um != 0) {
+            const uint32_t cnt = (uint32_t)__popcll(um);
+            if (qn + cnt <= GL_QUEUE) {
+                if (und) {
+                    const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u));
+                    queue[wv][pos] = make_uint2(bits16 | ((uint32_t)i << 16) | (und16 ? 1u << 30 : 0u) | (und24 ? 1u << 31 : 0u),
+                                                bits24 | ((uint32_t)lane << 24));
+                }
+                qn += cnt;
+            } else if (und) {  // a full queue: flat content, every lane is busy anyway
+                const int y = ys + i;
+                if (und16)
+                    count(hist16, 16, ring_settle(tile, LP, HALO, x0, y0, 16, offs[0], offs[1], bits16,
+                                                  ring_near<16>(pr, a.wtop16, a.wbot16, init16, lim16, ~bits16), y, x));
+                if (und24)
+                    count(hist24, 24, ring_settle(tile, LP, HALO, x0, y0, 24, offs[2], offs[3], bits24,
+                                                  ring_near<24>(pr, a.wtop24, a.wbot24, init24, lim24, ~bits24), y, x));
+            }
+        }
+    };
+    for (int i = 0; i < GL_ROWS; i += 2) {
+        if (ys + i >= a.H) break;
+        row(i, X16, Y16, X24, Y24);
+        if (ys + i + 1 >= a.H) break;
+        row(i + 1, Y16, X16, Y24, X24);
+    }
+    for (uint32_t qb = 0; qb < qn; qb += 64) {
+        if (qb + lane < qn) {
+            const uint2 e = queue[wv][qb + lane];
+            const int i = (int)((e.x >> 16) & 0xFFu), ql = (int)(e.y >> 24);
+            const int y = ys + i, xx = x0 + ql;
+            const uint8_t* pr = reinterpret_cast<const uint8_t*>(tile) + 4 * ((wv * GL_ROWS + i) * LP + ql);
+            const uint32_t c = tile[(wv * GL_ROWS + i + HALO) * LP + ql + HALO] & 0xFFFFu;
+            if (e.x & (1u << 30))
+                count(hist16, 16, ring_settle(tile, LP, HALO, x0, y0, 16, offs[0], offs[1], e.x & 0xFFFFu,
+                                              ring_near<16>(pr, a.wtop16, a.wbot16, a.margin16 - (c << 16), lim16, ~e.x), y, xx));
+            if (e.x & (1u << 31))
+                count(hist24, 24, ring_settle(tile, LP, HALO, x0, y0, 24, offs[2], offs[3], e.y & 0xFFFFFFu,
+                                              ring_near<24>(pr, a.wtop24, a.wbot24, a.margin24 - (c << 16), lim24, ~e.y), y, xx));
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * GL_BINS) {
+        const int64_t tileid = ((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int b = tid & (GL_BINS - 1);
+        const uint32_t* hist = tid < GL_BINS ? hist16 : hist24;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < GL_COPIES; ++k) v += hist[k * GL_HSTRIDE + b];
+        (tid < GL_BINS ? a.part16 : a.part24)[tileid * GL_BINS + b] = v;
+    }
+}
+
 // Per-frame sum of the tile histograms, in a fixed order.
 __global__ __launch_bounds__(256) void lbp_hist_reduce_kernel(const uint32_t* __restrict__ part, int tiles, int bins,
                                                               FrameAcc* __restrict__ acc, int hist_slot) {
@@ -307,14 +516,16 @@ __global__ __launch_bounds__(256) void lbp_hist_reduce_kernel(const uint32_t* __
 
 int lbp_generic_tiles(const Geom& g) { return ((g.W + GL_TILE - 1) / GL_TILE) * ((g.H + GL_TILE - 1) / GL_TILE); }
 size_t lbp_generic_part_bytes(const Geom& g, int n_frames) {
-    return (size_t)n_frames * lbp_generic_tiles(g) * GL_BINS * sizeof(uint32_t);
+    // (two sets: the fused kernel for the two extra radii leaves both histograms at once)
+    return (size_t)2 * n_frames * lbp_generic_tiles(g) * GL_BINS * sizeof(uint32_t);
 }
 
-bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
-                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out, int hist_slot) {
-    LbpGenArgs a;
-    a.gray = gray; a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.P = P;
-    a.off = off; a.part = part; a.codes = codes_out;
+// Cell geometry, 16.16 weights and error margin of every sample of (P, off); *ring says whether the geometry is that
+// of the compile-time tables for this P (P = 16 or 24).  Returns false when the radius needs more LDS than a tile has.
+static bool build_gen_args(const Geom& g, int P, const LbpOffsets& off, LbpGenArgs* ap, size_t* lds_out, bool* ring) {
+    LbpGenArgs& a = *ap;
+    a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows; a.P = P;
+    a.off = off;
     // cell geometry and weights from the nominal offsets (pixel (0,0)): the per-pixel fp64 weights differ from
     // these by rounding in the 13th digit, which the guard in the margin covers
     int halo = 1;
@@ -336,6 +547,7 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
     // odd pitch in 32-bit entries: consecutive tile rows start in different LDS banks
     const int lpitch = (GL_TILE + 2 * halo) | 1;
     const size_t lds = (size_t)(GL_TILE + 2 * halo) * lpitch * sizeof(uint32_t);
+    *lds_out = lds;
     if (lds > 52 * 1024) return false;  // radius beyond what one tile with its halo can hold (static LDS takes 11 of the 64 KB)
     a.halo = halo; a.lpitch = lpitch;
     for (int p = 0; p < 24; ++p) { a.otop[p] = 0; a.obot[p] = 0; a.wtop[p] = 0; a.wbot[p] = 0; a.lim[p] = 0; }
@@ -372,19 +584,30 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
     }
     a.margin = (uint32_t)ceil(worst) + 2u;
     for (int p = 0; p < P; ++p) a.lim[p] = (dr1[p] == 0 && dc1[p] == 0) ? 0u : 2u * a.margin + 1u;
-    dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
     // the compile-time cell tables apply when this launch's geometry is theirs (it is for R = 2 at P = 16 and R = 3 at
     // P = 24, whatever rounding of the offsets the caller's platform produced is checked here, not assumed)
-    auto ring_ok = [&](auto ring) {
-        typedef decltype(ring) G;
+    auto ring_ok = [&](auto rg) {
+        typedef decltype(rg) G;
         if (halo != G::HALO || lpitch != G::LPITCH) return false;
         for (int p = 0; p < P; ++p)
             if (fr[p] != G::fr(p) || fc[p] != G::fc(p) || dr1[p] != G::d1(p) || dc1[p] != G::d1(p)) return false;
         return true;
     };
-    if (P == 16 && ring_ok(Ring<16>()))
+    *ring = (P == 16 && ring_ok(Ring<16>())) || (P == 24 && ring_ok(Ring<24>()));
+    return true;
+}
+
+bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, int P, const LbpOffsets& off,
+                        uint32_t* part, FrameAcc* acc, uint8_t* codes_out, int hist_slot) {
+    LbpGenArgs a;
+    size_t lds = 0;
+    bool ring = false;
+    if (!build_gen_args(g, P, off, &a, &lds, &ring)) return false;
+    a.gray = gray; a.part = part; a.codes = codes_out;
+    dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
+    if (P == 16 && ring)
         hipLaunchKernelGGL((lbp_generic_kernel<16, true>), grid, dim3(256), lds, s, a);
-    else if (P == 24 && ring_ok(Ring<24>()))
+    else if (P == 24 && ring)
         hipLaunchKernelGGL((lbp_generic_kernel<24, true>), grid, dim3(256), lds, s, a);
     else
         switch (P) {
@@ -394,6 +617,32 @@ bool launch_lbp_generic(hipStream_t s, const uint8_t* gray, int n_frames, const 
             default: hipLaunchKernelGGL((lbp_generic_kernel<0, false>), grid, dim3(256), lds, s, a); break;
         }
     hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, part, lbp_generic_tiles(g), P + 2, acc, hist_slot);
+    return true;
+}
+
+bool launch_lbp_rings(hipStream_t s, const uint8_t* gray, int n_frames, const Geom& g, const LbpOffsets& off16,
+                      const LbpOffsets& off24, uint32_t* part, FrameAcc* acc) {
+    LbpGenArgs a16, a24;
+    size_t lds = 0;
+    bool ring16 = false, ring24 = false;
+    // the fused kernel is written for the cell geometry of the compile-time tables; anything else takes two launches
+    if (!build_gen_args(g, 16, off16, &a16, &lds, &ring16) || !build_gen_args(g, 24, off24, &a24, &lds, &ring24) ||
+        !ring16 || !ring24)
+        return launch_lbp_generic(s, gray, n_frames, g, 16, off16, part, acc, nullptr, 1) &&
+               launch_lbp_generic(s, gray, n_frames, g, 24, off24, part, acc, nullptr, 2);
+    LbpRingsArgs a;
+    a.gray = gray; a.H = g.H; a.W = g.W; a.gpitch = g.gpitch; a.grows = g.grows;
+    a.margin16 = a16.margin; a.margin24 = a24.margin;
+    for (int p = 0; p < 16; ++p) { a.wtop16[p] = a16.wtop[p]; a.wbot16[p] = a16.wbot[p]; }
+    for (int p = 0; p < 24; ++p) { a.wtop24[p] = a24.wtop[p]; a.wbot24[p] = a24.wbot[p]; }
+    a.off16 = off16; a.off24 = off24;
+    const int tiles = lbp_generic_tiles(g);
+    a.part16 = part;
+    a.part24 = part + (size_t)n_frames * tiles * GL_BINS;
+    dim3 grid((g.W + GL_TILE - 1) / GL_TILE, (g.H + GL_TILE - 1) / GL_TILE, n_frames);
+    hipLaunchKernelGGL(lbp_rings_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, a.part16, tiles, 18, acc, 1);
+    hipLaunchKernelGGL(lbp_hist_reduce_kernel, dim3(n_frames), dim3(256), 0, s, a.part24, tiles, 26, acc, 2);
     return true;
 }
 
