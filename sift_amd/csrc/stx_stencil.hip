@@ -244,8 +244,7 @@ struct RowD {
     uint32_t hg;            // horizontal [1 4 6 4 1] (reflected border)
     uint32_t rs;            // horizontal 3-sum (reflected border)
     uint32_t z0;            // the pixel pair (x,x+1), zero outside the image (LBP view)
-    // LBP view (zero outside the image), bit 15 of each half set: pairs (x,x+1) (x-1,x) (x+1,x+2)
-    uint32_t zh0, zhm, zhp;
+    uint32_t zm, zp;        // LBP view of the pairs (x-1,x) and (x+1,x+2)
     // linear parts of the diagonal samples: with rows r-1, r, r+1 and the pairs m = (x-1,x), p = (x+1,x+2),
     //   rp = 70 p + 29 z0, rm = 70 m + 29 z0      (contribution of a row above / below the centre row)
     //   gp = 29 p - 128 z0 + 0x8002, gm likewise    (contribution of the centre row itself)
@@ -350,9 +349,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
             const uint32_t e = pk_mad_op(o.z0, 0xFF80FF80u, 0x80028002u);  // 0x8002 - 128 c per half
             o.gp = pk_mad<29>(zp1, e);
             o.gm = pk_mad<29>(zm1, e);
-            o.zh0 = o.z0 | HH;
-            o.zhm = zm1 | HH;
-            o.zhp = zp1 | HH;
+            o.zm = zm1;
+            o.zp = zp1;
         }
     };
 
@@ -399,7 +397,8 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
     // at most 63; 16 rows add at most 32 (whichever lane counts a pixel in a dense block, it is one of its own) and
     // the second stage at most QUEUE_ITEMS / 64 = 8 more: the first half of the strip is set aside after its 16 rows.
     uint32_t hist_a = 0, hist_b = 0, hist_a0 = 0, hist_b0 = 0;
-    uint32_t hp_s = 0, hp_q = 0, ad_s = 0, gr_s = 0;
+    uint32_t hp_pk = 0, hp_q = 0, ad_s = 0, gr_pk = 0;
+    static_assert(WAVE_ROWS * 255 < 65536, "a strip's sums of 8-bit values fit the halves of a word");
     uint32_t accS = 0, accC = 0;      // Canny bits of up to 16 rows, first row highest, per half
     uint32_t accS0 = 0, accC0 = 0;    // rows 0..15 of the strip
 
@@ -458,9 +457,10 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 {
                     const uint32_t sum3 = rw[1].rs + rw[2].rs + rw[3].rs;  // at most 2295 per half
                     const uint32_t v = pk_min(pk_sub_sat(pk_mul<9>(c2), sum3), 0x00FF00FFu);
-                    hp_s = sum_u16(v, hp_s);
+                    // (halves of at most 255, 32 rows: plain adds on the whole word, split at the end of the strip)
+                    hp_pk += v;
                     hp_q = dot2(v, v, hp_q);
-                    gr_s = sum_u16(c2, gr_s);
+                    gr_pk += c2;
                 }
                 // ---- Gaussian residual
                 {
@@ -471,10 +471,13 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
                 }
                 // ---- LBP (P=8, R=1), first stage: bit 15 of each half of a difference is "sample >= centre"
                 if (DO_LBP) {
-                    const uint32_t a0 = rw[2].zhp - c2;  // sample 0 (0,+1)
-                    const uint32_t a2 = rw[1].zh0 - c2;  // sample 2 (-1,0)
-                    const uint32_t a4 = rw[2].zhm - c2;  // sample 4 (0,-1)
-                    const uint32_t a6 = rw[3].zh0 - c2;  // sample 6 (+1,0)
+                    // (neighbour | 0x8000) - centre per half, as one plain subtraction of the centre word less bit 15
+                    // of each half: a half's result is at least 0x8000 - 255, so nothing borrows from the other half
+                    const uint32_t cm = c2 - HH;
+                    const uint32_t a0 = rw[2].zp - cm;  // sample 0 (0,+1)
+                    const uint32_t a2 = rw[1].z0 - cm;  // sample 2 (-1,0)
+                    const uint32_t a4 = rw[2].zm - cm;  // sample 4 (0,-1)
+                    const uint32_t a6 = rw[3].z0 - cm;  // sample 6 (+1,0)
                     const uint32_t f1 = rw[1].rp + rw[2].gp;  // (-.7,+.7): 0x8002 + N'
                     const uint32_t f3 = rw[1].rm + rw[2].gm;  // (-.7,-.7)
                     const uint32_t f5 = rw[3].rm + rw[2].gm;  // (+.7,-.7)
@@ -717,7 +720,7 @@ __device__ __forceinline__ void march(const StencilArgs& a, const uint8_t* tile,
         w[2] = (((hist_a >> 24) & 63u) + ((hist_a0 >> 24) & 63u)) | ((((hist_b) & 63u) + ((hist_b0) & 63u)) << 16);  // 4, 5
         w[3] = bin2(hist_b, hist_b0, 1);                                                    // bins 6, 7
         w[4] = bin2(hist_b, hist_b0, 3);                                                    // bins 8, 9
-        w[5] = hp_s; w[6] = hp_q; w[7] = ad_s; w[8] = gr_s;
+        w[5] = (hp_pk & 0xFFFFu) + (hp_pk >> 16); w[6] = hp_q; w[7] = ad_s; w[8] = (gr_pk & 0xFFFFu) + (gr_pk >> 16);
         wave_total9(w);
         if (lane == 63) {
 #pragma unroll
