@@ -795,27 +795,42 @@ int refine_fft64(stx_ctx* c, Slot& sl, const Prepared& pr, const int* frames, in
         if ((rc = get_twiddles64(c, pr.plan_w, &tw_w)) != STX_OK) return rc;
         if ((rc = get_twiddles64(c, pr.plan_h, &tw_h)) != STX_OK) return rc;
         try {
-            c->part64_host.resize((size_t)g.fwh * batch);
+            c->part64_host.resize((size_t)g.fwh * n_redo);
         } catch (const std::bad_alloc&) {
             return fail(c, STX_ERR_NOMEM, "out of host memory");
         }
         part_host = c->part64_host.data();
     }
-    for (int i0 = 0; i0 < n_redo; i0 += batch) {
-        const int nb = std::min(batch, n_redo - i0);
-        launch_fft64(c->stream, (const uint8_t*)sl.gray.p, frames + i0, nb, g, pr.plan_w, pr.plan_h, tw_w, tw_h, w);
-        HIPCHK(c, hipMemcpyAsync(part_host, w.part, w.part_bytes * nb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipGetLastError());
+    // Every batch is queued before the host waits once (the batches reuse the device buffers in stream order, and each
+    // one's column sums are copied to their own place on the host); the allocation-free path has staging for one
+    // frame's sums and waits per frame.
+    const bool per_batch_wait = sl.gray.fixed;
+    auto sum_batch = [&](int i0, int nb, const double2* host) {
         for (int b = 0; b < nb; ++b) {
             const int f = frames[i0 + b];
-            const double2* ph = part_host + (size_t)b * g.fwh;
+            const double2* ph = host + (size_t)b * g.fwh;
             double s = 0.0, s2 = 0.0;  // fixed order: reproducible
             for (int k = 0; k < g.fwh; ++k) { s += ph[k].x; s2 += ph[k].y; }
             sl.acc_host[f].fft_sum = s;
             sl.acc_host[f].fft_sumsq = s2;
             sl.acc_host[f].pad0 = 1u;
         }
+    };
+    for (int i0 = 0; i0 < n_redo; i0 += batch) {
+        const int nb = std::min(batch, n_redo - i0);
+        launch_fft64(c->stream, (const uint8_t*)sl.gray.p, frames + i0, nb, g, pr.plan_w, pr.plan_h, tw_w, tw_h, w);
+        double2* dst = per_batch_wait ? part_host : part_host + (size_t)i0 * g.fwh;
+        HIPCHK(c, hipMemcpyAsync(dst, w.part, w.part_bytes * nb, hipMemcpyDeviceToHost, c->stream));  // part_bytes = fwh double2
+        if (per_batch_wait) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipGetLastError());
+            sum_batch(i0, nb, part_host);
+        }
+    }
+    if (!per_batch_wait) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        for (int i0 = 0; i0 < n_redo; i0 += batch) sum_batch(i0, std::min(batch, n_redo - i0), part_host + (size_t)i0 * g.fwh);
     }
     c->fft64_frames += (uint64_t)n_redo;
     return STX_OK;

@@ -24,10 +24,14 @@ __device__ __forceinline__ Cpx<T> cmul_mi(Cpx<T> a) { return mk<T>(a.y, -a.x); }
 
 // One Stockham pass of radix R over nb transforms of length n.
 // in/out: [nb][n] (LDS or global memory); ns = product of the radices already applied; tw[j] = exp(-2 pi i j / n).
-template <class T>
-__device__ void fft_pass(const Cpx<T>* __restrict__ in, Cpx<T>* __restrict__ out, int n, int R, int ns, int nb,
-                         const Cpx<T>* __restrict__ tw, int tid, int nthreads) {
+// NC / RC / NSC: the same three numbers as compile-time constants (0 = take the run-time argument): with them the
+// index arithmetic of a butterfly -- two divisions and a remainder by run-time numbers otherwise, as many instructions
+// as the butterfly itself -- folds into shifts and multiplications.
+template <class T, int NC = 0, int RC = 0, int NSC = 0>
+__device__ __forceinline__ void fft_pass(const Cpx<T>* __restrict__ in, Cpx<T>* __restrict__ out, int n_rt, int R_rt, int ns_rt,
+                                         int nb, const Cpx<T>* __restrict__ tw, int tid, int nthreads) {
     typedef Cpx<T> C;
+    const int n = NC ? NC : n_rt, R = RC ? RC : R_rt, ns = NSC ? NSC : ns_rt;
     const int m = n / R;            // butterflies per transform
     const int twstep = n / (ns * R);
     if (R != 2 && R != 3 && R != 4 && R != 5) {
@@ -54,10 +58,13 @@ __device__ void fft_pass(const Cpx<T>* __restrict__ in, Cpx<T>* __restrict__ out
         }
         return;
     }
-    for (int b = 0; b < nb; ++b) {
-        const C* ib = in + b * n;
-        C* ob = out + b * n;
-        for (int j = tid; j < m; j += nthreads) {
+    // the butterflies of all nb transforms handed out together: a pass of m butterflies per transform leaves the
+    // workgroup's last round of a transform nearly idle when m is a little more than a multiple of its size
+    {
+        for (int idx = tid; idx < nb * m; idx += nthreads) {
+            const int b = nb == 1 ? 0 : idx / m, j = idx - b * m;
+            const C* ib = in + b * n;
+            C* ob = out + b * n;
             const int k = j % ns;
             const int o = (j - k) * R + k;
             const int t1 = k * twstep;
@@ -158,6 +165,37 @@ __device__ void fft_bluestein(Cpx<T>* work, int n, int m, const Cpx<T>* __restri
     }
     for (int k = tid; k < n; k += nthreads) work[k] = cmul(work[k], chirp[k]);
     __syncthreads();
+}
+
+// The plans make_fft_plan gives the four common frame dimensions, as compile-time constants.
+template <class T, int N, int R0, int R1, int R2, int R3, int R4, int R5>
+__device__ __forceinline__ Cpx<T>* fft_run_fixed(Cpx<T>* a, Cpx<T>* b, int nb, const Cpx<T>* tw, int tid, int nthreads) {
+    static_assert(R0 * R1 * R2 * R3 * R4 * R5 == N, "radices must multiply to N");
+    fft_pass<T, N, R0, 1>(a, b, N, R0, 1, nb, tw, tid, nthreads);
+    __syncthreads();
+    fft_pass<T, N, R1, R0>(b, a, N, R1, R0, nb, tw, tid, nthreads);
+    __syncthreads();
+    fft_pass<T, N, R2, R0 * R1>(a, b, N, R2, R0 * R1, nb, tw, tid, nthreads);
+    __syncthreads();
+    fft_pass<T, N, R3, R0 * R1 * R2>(b, a, N, R3, R0 * R1 * R2, nb, tw, tid, nthreads);
+    __syncthreads();
+    fft_pass<T, N, R4, R0 * R1 * R2 * R3>(a, b, N, R4, R0 * R1 * R2 * R3, nb, tw, tid, nthreads);
+    __syncthreads();
+    if constexpr (R5 > 1) {
+        fft_pass<T, N, R5, R0 * R1 * R2 * R3 * R4>(b, a, N, R5, R0 * R1 * R2 * R3 * R4, nb, tw, tid, nthreads);
+        __syncthreads();
+        return a;
+    }
+    return b;
+}
+// true if plan is the one fft_run_fixed<.., N, R...> runs
+inline bool fft_plan_is(const FftPlan& p, int n, int r0, int r1, int r2, int r3, int r4, int r5) {
+    const int r[6] = {r0, r1, r2, r3, r4, r5};
+    const int np = r5 > 1 ? 6 : 5;
+    if (p.n != n || p.bz_m || p.npass != np) return false;
+    for (int i = 0; i < np; ++i)
+        if (p.radix[i] != r[i]) return false;
+    return true;
 }
 
 // runs the whole plan; returns the buffer that holds the result

@@ -184,7 +184,7 @@ inline float fft_small_threshold(int fh, int fw) { return (float)(64.0 * fft_f32
 // The same transform and statistic in double precision for single frames (stx_fft64.hip): used for the frames whose
 // spectrum has enough near-zero bins that fp32 rounding noise would show in the statistic.
 struct Fft64Work {
-    void* spec = nullptr;     // [fh][fwh] double2
+    void* spec = nullptr;     // half spectrum as double2, in blocks of four columns
     void* scratch = nullptr;  // second pass buffer of the workgroups when it does not fit LDS
     void* part = nullptr;     // [fwh] double2 (sum, sum of squares) per column, weighted
     size_t spec_bytes = 0, scratch_bytes = 0, part_bytes = 0;
