@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 PREWARM_STEPS = 12     # untimed clips before the W warm-up steps (workspace sizing, GPU clocks)
 MAX_RESIDENT_BYTES = 48 << 30  # distinct input clips kept in HBM per rank
 
+_shape = (0, 0)  # frame size of the run (set by main)
+
 CONFIGS = {
     # name: frames per step, height, width, FFT crop (0 = whole frame), extended statistics, BASELINE row
     "1080p": dict(frames=150, h=1080, w=1920, fft=0, extended=False, row="configs[2]"),
@@ -130,6 +132,8 @@ def main() -> None:
                     help="bracket every kernel with HIP events in the timed region, not only the dominant group's "
                          "(costs a few percent of throughput: each event pair delays its stream's next kernel)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = the library's choice)")
+    ap.add_argument("--no-other-content", action="store_true",
+                    help="skip the short runs on the other synthetic content classes (reported under other_content)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the CPU baseline legs")
     args = ap.parse_args()
 
@@ -170,6 +174,8 @@ def main() -> None:
     if args.steps <= 0:
         args.steps = (cfg["total_clips"] + world - 1) // world if streaming else 40
     h, w = args.height or cfg["h"], args.width or cfg["w"]
+    global _shape
+    _shape = (h, w)
     nf = args.frames or cfg["frames"]
     fh = fw = cfg["fft"]
     fh, fw = (fh or h), (fw or w)
@@ -417,11 +423,40 @@ def main() -> None:
                 result["config1_cpu_reference_path"] = config1(ctx, args.cpu_seconds * 0.3)
         if world == 1 and args.host_fed:
             result["host_fed"] = host_fed(ctx, clips[0], nf, h, w)
+        if world == 1 and args.config == "1080p" and args.kind == "natural" and not args.no_other_content:
+            result["other_content"] = other_content(ctx, clips, run_steps, nf, fps)  # (overwrites the clips: last)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def other_content(ctx, clips, run_steps, nf: int, natural_fps: float) -> dict:
+    """Frames/s of the same pipeline on the other synthetic content classes (a few clips each, after the headline's
+    timed region): how far the rate depends on what the frames show -- exact LBP ties (flat, tie), dense edges (noise,
+    step), spectra with exactly-zero bins that send every frame through the fp64 transform (ramp)."""
+    import torch
+
+    from sift_amd.synth import KIND_ID, KINDS
+
+    out = {"natural": natural_fps}
+    ctx.get_timing(reset=True)
+    for kind in KINDS:
+        if kind == "natural":
+            continue
+        ctx.set_canny_mode("auto")  # forget what the class before taught the adaptive placement of Canny's suppression
+        for i, t in enumerate(clips[:8]):  # the clips the steps below go through
+            ctx.synth_device(t.data_ptr(), KIND_ID[kind], 0x5EED0000 + 2, i, 0, nf, *_shape)
+        run_steps(4, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(8, False)
+        torch.cuda.synchronize()
+        out[kind] = 8 * nf / (time.perf_counter() - t0)
+    out["fft64_frames"] = ctx.get_timing(reset=True)["fft64_frames"]
+    out["slowest_over_fastest"] = min(v for k, v in out.items() if k in KINDS) / max(v for k, v in out.items() if k in KINDS)
+    return out
 
 
 def spot_check(all_rows: np.ndarray, kind: str, seed: int, h: int, w: int, nf: int) -> dict:
