@@ -7,7 +7,7 @@ Both counters come in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte request as 6
 kernels whose loads are 12 bytes per lane or wider (gray, the stencil pass that reads BGR frames, FFT rows
 prefetch aside, FFT cols) are doubled; narrow-load kernels (hysteresis and the suppression on the flooded set, which
 is counted with it, FFT rows byte/halfword loads) are left as counted, so their true read traffic lies between the raw
-and the doubled figure.  "clears" are the runtime's fill kernels (accumulators, flags, the second candidate map).
+and the doubled figure.  "clears" are the chunk's one init kernel (accumulators, flags) and whatever fill kernels the runtime still launches.
 """
 import collections
 import csv
@@ -19,7 +19,7 @@ import sys
 GROUPS = (("gray_kernel", "gray", True), ("stencil_kernel", "stencil", True), ("lbp_generic", "lbp_generic", False),
           ("hyst_pass_kernel", "hysteresis", False), ("hyst_finish_kernel", "hysteresis", False),
           ("nms_collect_kernel", "hysteresis", False), ("nms_apply_kernel", "hysteresis", False),
-          ("fillBufferAligned", "clears", False), ("rows_kernel", "fft_rows", False), ("cols_kernel", "fft_cols", True),
+          ("fillBufferAligned", "clears", False), ("chunk_init", "clears", False), ("rows_kernel", "fft_rows", False), ("cols_kernel", "fft_cols", True),
           ("frame_reduce", "reduce", False))
 
 

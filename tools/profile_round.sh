@@ -22,7 +22,7 @@ step latency
 timeout -k 10 200 python3 tools/latency.py > $OUT/latency.txt 2>&1 || exit 1
 cd /tmp
 step kernel trace
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-other-content > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 step pmc fetch
 timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/prof1.py > $OUT/pmc_fetch.log 2>&1 || exit 1
 step pmc write

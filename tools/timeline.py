@@ -7,7 +7,7 @@ import csv
 import sys
 
 NAMES = (("stencil", "stencil"), ("gray_kernel", "gray"), ("rows_kernel", "fft_rows"), ("cols_kernel", "fft_cols"),
-         ("hyst_pass", "hysteresis"), ("hyst_finish", "hysteresis"), ("nms_collect", "suppression"), ("nms_apply", "suppression"), ("frame_reduce", "reduce"), ("synth", "synth"),
+         ("hyst_pass", "hysteresis"), ("hyst_finish", "hysteresis"), ("nms_collect", "suppression"), ("nms_apply", "suppression"), ("frame_reduce", "reduce"), ("chunk_init", "init"), ("synth", "synth"),
          ("copyBuffer", "copy"), ("fillBuffer", "fill"), ("fft64", "fft64"))
 
 
@@ -32,7 +32,7 @@ def main():
     t0 = sel[0][0]
     print("concurrent clips (times in us from the first kernel of a clip)")
     for s, e, n, q in sel:
-        if n in ("fill", "copy", "reduce"):
+        if n in ("fill", "copy", "reduce", "init"):
             continue
         beside = sorted({m for (s2, e2, m, _) in sel if m != n and s2 < e and e2 > s and m not in ("fill", "copy")})
         print(f"  {(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  q{q} {n:10s} beside: {', '.join(beside) or '-'}")
