@@ -115,8 +115,13 @@ def test_lbp_near_tie_lattice_vs_skimage(ctx, coracle):
             assert np.array_equal(codes, want), (oy, ox, P, int((codes != want).sum()))
 
 
-def test_score_sets_golden(det):
-    gold = json.load(open(os.path.join(GOLD, "score_sets.json")))
+@pytest.mark.parametrize("shift,fname", [(15, "score_sets.json"), (14, "score_sets_gray14.json")])
+def test_score_sets_golden(ctx, shift, fname):
+    from sift_amd.texture import TextureNoiseDetector
+    gold = json.load(open(os.path.join(GOLD, fname)))
+    prm = ctx.default_params()
+    prm.gray_shift = shift
+    det = TextureNoiseDetector(device=0, params=prm)
     for si, (name, kind, n, h, w) in enumerate(SCORE_SETS):
         entry = gold[name]
         frames = list(synth_clip(kind, SEED, 10 + si, n, h, w)) if n else []
