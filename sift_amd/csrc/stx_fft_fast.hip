@@ -532,8 +532,13 @@ struct RowsArgs {
 //   DIRECT (one transform per wave, aligned rows, N/R0 in {64,128,256}): the first pass takes its inputs
 //   from the prefetch registers, the last pass splits and stores from registers (see above);
 //   otherwise the signal is staged in LDS first; sub-wave transforms also split through LDS.
+#ifdef STX_ROWS_WAVES  // (experiments: hold the row kernel to the registers of that many waves per SIMD)
+#define STX_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(STX_ROWS_WAVES, STX_ROWS_WAVES)))
+#else
+#define STX_ROWS_ATTR
+#endif
 template <class P, bool DIRECT>
-__global__ __launch_bounds__(64) void rows_kernel(RowsArgs a) {
+__global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[P::TPW * P::S];
     constexpr int N = P::N, LPT = P::LPT;
     constexpr bool PAIRS = (LPT == 64);  // fused last pass
