@@ -137,6 +137,7 @@ struct stx_ctx {
     std::map<int, float2*> twiddles;
     int chunk_override = 0;
     bool concurrent_fft = true;
+    bool streaming = false;  // stx_synth_device_async has been used: chunks record the end of their stencil pass for it
     // the stencil pass converts BGR itself where it can; SIFT_TEXTURE_SEPARATE_GRAY=1 in the environment keeps the
     // separate gray pass for every call (measurements, and tests that run both paths on one input)
     bool fuse_gray = true;
@@ -644,7 +645,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         sp.end();
     }
     // (a raw chunk's second-stream work waits for the row pass instead: no event between the stencil and the row pass)
-    if (!(sl.raw && fused_flow)) HIPCHK(c, hipEventRecord(sl.stencil_done, s));
+    if (!(sl.raw && fused_flow) || c->streaming) HIPCHK(c, hipEventRecord(sl.stencil_done, s));
     if (!lbp81) {
         Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 2, s);
         const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, (uint32_t*)sl.lpart.p, acc,
@@ -1586,6 +1587,12 @@ int stx_synth_device_async(stx_ctx* c, uint8_t* bgr_dev, int kind, uint64_t seed
     // progress the stencil pass waits for: a call that follows reads finished frames, and until then the generator
     // runs beside whatever the device is busy with
     hipStream_t st = c->concurrent_fft ? c->stream_pre : c->stream;
+    // The generator is bound by vector issue and by HBM stores; of the chunk in flight, the stencil pass is bound by
+    // vector issue too, the FFT row pass by stores alone: the generator starts when that chunk's stencil pass ends
+    // and runs beside its row pass.
+    if (c->streaming && c->prev_chunk && st != c->stream)
+        HIPCHK(c, hipStreamWaitEvent(st, c->prev_chunk->stencil_done, 0));
+    c->streaming = true;
     Span sp(c, &c->synth_spans, STX_K_SYNTH, 1, st);
     launch_synth(st, bgr_dev, kind, seed, video, frame0, n_frames, h, w);
     sp.end();
