@@ -373,7 +373,9 @@ __global__ __launch_bounds__(256) void lbp_rings_kernel(LbpRingsArgs a) {
     __shared__ double offs[4][24];  // rp16, cp16, rp24, cp24
     // undecided pixels of each wave's strip: .x = bits of ring 16 | row << 16 | undecided in ring 16 << 30 | in ring 24
     // << 31, .y = bits of ring 24 | lane << 24
-    __shared__ uint2 queue[4][GL_QUEUE];
+    // (128 entries per 1024-pixel strip: with the smaller queue a fifth workgroup fits a compute unit's LDS)
+    constexpr int RQ = 128;
+    __shared__ uint2 queue[4][RQ];
     const int frame = blockIdx.z;
     const int x0 = blockIdx.x * GL_TILE, y0 = blockIdx.y * GL_TILE;
     const int tid = threadIdx.x;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void lbp_rings_kernel(LbpRingsArgs a) {
         const unsigned long long um = __ballot(und);
         if (um != 0) {
             const uint32_t cnt = (uint32_t)__popcll(um);
-            if (qn + cnt <= GL_QUEUE) {
+            if (qn + cnt <= RQ) {
                 if (und) {
                     const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u));
                     queue[wv][pos] = make_uint2(bits16 | ((uint32_t)i << 16) | (und16 ? 1u << 30 : 0u) | (und24 ? 1u << 31 : 0u),
