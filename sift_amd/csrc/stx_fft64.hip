@@ -379,11 +379,18 @@ __global__ __launch_bounds__(T) void rows_kernel(Rows64Args a) {
     __syncthreads();
     transform<P>(buf, a.tw, tid);
     // rows ra and rb from the packed transform: A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i
-    for (int k = tid; k < a.fwh; k += T) {
-        const cd zk = buf[k], zc = buf[k ? n - k : 0];
-        const int64_t o = f64_spec_index(k, ra, a.fh);
-        spec[o] = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y)};
-        if (inb) spec[o + F64_CB] = cd{0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x)};
+    // A block row of the spectrum is four bins, 64 bytes; rows ra and rb of a block are the two halves of one 128-byte
+    // line.  Eight consecutive threads write one line (four bins of row ra, the same four of row rb): whole lines from
+    // one instruction stream at 5.9 TB/s, half lines from two at 3.7.
+    static_assert(F64_CB == 4, "eight threads per line");
+    const int items = 2 * ((a.fwh + F64_CB - 1) / F64_CB * F64_CB);
+    for (int e = tid; e < items; e += T) {
+        const int l = e & 7, h = l >> 2, k = (e >> 3) * F64_CB + (l & 3);
+        if (k < a.fwh && (h == 0 || inb)) {
+            const cd zk = buf[k], zc = buf[k ? n - k : 0];
+            spec[f64_spec_index(k, ra, a.fh) + h * F64_CB] =
+                h ? cd{0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x)} : cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y)};
+        }
     }
 }
 

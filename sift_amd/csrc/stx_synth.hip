@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64) void synth_natural4_kernel(uint32_t* __restrict
         const uint32_t d0 = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
         const uint32_t d1 = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
         const uint32_t d2 = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
-        o[0] = d0; o[1] = d1; o[2] = d2;
+        // one 12-byte store, marked non-temporal: nothing reads a frame before the whole clip is written
+        __builtin_nontemporal_store(d0, o); __builtin_nontemporal_store(d1, o + 1); __builtin_nontemporal_store(d2, o + 2);
     }
 }
 

@@ -41,3 +41,18 @@ def test_4k_full_frame_transform(ctx):
     # the gray plane as the library computes it, through the debug entry point, then numpy's complex128 transform
     gray, _, _ = ctx.debug_planes(f)
     assert r.frequency_anomaly == pytest.approx(_ref(gray), rel=1e-5)
+
+
+@pytest.mark.parametrize("hw", [(67, 1920), (67, 1280), (33, 640), (135, 960), (1081, 1920)])
+def test_row_pairs_with_an_odd_height(ctx, hw):
+    """The row pass transforms two image rows at a time and writes both rows' bins of a column block as one line;
+    the last row of an odd-height frame has no partner, and the next frame's first line follows it directly."""
+    h, w = hw
+    rng = np.random.default_rng(h * 4096 + w)
+    frames = []
+    for _ in range(3):
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        frames.append((g, np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))))
+    r = ctx.analyze_frames([b for _, b in frames])
+    for (g, _), m in zip(frames, r):
+        assert m.frequency_anomaly == pytest.approx(_ref(g), rel=1e-5), hw

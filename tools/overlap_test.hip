@@ -8,6 +8,67 @@
 #include "../sift_amd/csrc/stx_internal.h"
 using namespace stx;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+// diagnostic neighbours: one-wave workgroups that only store, only load, or only issue vector instructions
+__global__ __launch_bounds__(64) void store_only(float4* out, int per_wg) {
+    float4* o = out + (size_t)blockIdx.x * per_wg * 64 + threadIdx.x;
+    const float4 v = make_float4(blockIdx.x, threadIdx.x, 1.f, 2.f);
+    for (int i = 0; i < per_wg; ++i) o[(size_t)i * 64] = v;
+}
+__global__ __launch_bounds__(64) void store_nt(float4* out, int per_wg) {
+    float4* o = out + (size_t)blockIdx.x * per_wg * 64 + threadIdx.x;
+    const float4 v = make_float4(blockIdx.x, threadIdx.x, 1.f, 2.f);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 vv = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < per_wg; ++i) __builtin_nontemporal_store(vv, reinterpret_cast<f4*>(&o[(size_t)i * 64]));
+}
+__global__ __launch_bounds__(64) void load_nt(const float4* in, float* sink, int per_wg) {
+    const float4* p = in + (size_t)blockIdx.x * per_wg * 64 + threadIdx.x;
+    float acc = 0.f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int i = 0; i < per_wg; ++i) { const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(&p[(size_t)i * 64])); acc += v.x + v.y + v.z + v.w; }
+    if (acc == 1234.5f) sink[0] = acc;
+}
+// the row pass's shape: a store instruction covers eight full 128-byte lines, 540 lines apart (one per column block)
+template <bool NT>
+__global__ __launch_bounds__(64) void store_lines(float4* out, int per_wg, int nwg) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const size_t blk = blockIdx.x / 540, row = blockIdx.x % 540;   // 540 row pairs of a frame, 8 column blocks per instruction
+    f4* o = reinterpret_cast<f4*>(out) + (blk * per_wg * 8 * 540 + row) * 8 + (size_t)(lane >> 3) * 540 * 8 + (lane & 7);
+    const f4 v = {(float)blockIdx.x, (float)lane, 1.f, 2.f};
+    for (int i = 0; i < per_wg; ++i) {
+        if (NT) __builtin_nontemporal_store(v, o + (size_t)i * 8 * 540 * 8); else o[(size_t)i * 8 * 540 * 8] = v;
+    }
+}
+// the same bytes as 8-byte stores: a 64-byte half line per eight lanes, two instructions per line
+template <bool NT>
+__global__ __launch_bounds__(64) void store_halves(float2* out, int per_wg, int nwg) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const size_t blk = blockIdx.x / 540, row = blockIdx.x % 540;
+    f2* o = reinterpret_cast<f2*>(out) + ((blk * per_wg * 4 * 540 + row) * 8) * 2 + (size_t)(lane >> 3) * 540 * 16 + (lane & 7);
+    const f2 v = {(float)blockIdx.x, (float)lane};
+    for (int i = 0; i < per_wg; ++i) {
+        f2* q = o + (size_t)i * 8 * 540 * 16;
+        if (NT) { __builtin_nontemporal_store(v, q); __builtin_nontemporal_store(v, q + 8); } else { q[0] = v; q[8] = v; }
+    }
+}
+__global__ __launch_bounds__(256) void store_wg256(float4* out, int per_wg) {
+    float4* o = out + (size_t)blockIdx.x * per_wg * 256 + threadIdx.x;
+    const float4 v = make_float4(blockIdx.x, threadIdx.x, 1.f, 2.f);
+    for (int i = 0; i < per_wg; ++i) o[(size_t)i * 256] = v;
+}
+__global__ __launch_bounds__(64) void load_only(const float4* in, float* sink, int per_wg) {
+    const float4* p = in + (size_t)blockIdx.x * per_wg * 64 + threadIdx.x;
+    float acc = 0.f;
+    for (int i = 0; i < per_wg; ++i) { const float4 v = p[(size_t)i * 64]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 1234.5f) sink[0] = acc;
+}
+__global__ __launch_bounds__(64) void valu_only(float* sink, int iters) {
+    float a = threadIdx.x, b = blockIdx.x, c = 1.0001f, d = 0.5f;
+    for (int i = 0; i < iters; ++i) { a = a * c + d; b = b * c + a; d = d * c + b; c = c * 0.99999f + 1e-6f; }
+    if (a + b + c + d == 1234.5f) sink[0] = a;
+}
 int main(int argc, char** argv) {
     const int h = argc > 1 ? atoi(argv[1]) : 720, w = argc > 2 ? atoi(argv[2]) : 1280, F = argc > 3 ? atoi(argv[3]) : 150;
     Geom g;
@@ -33,7 +94,13 @@ int main(int argc, char** argv) {
     fft_fill_table(pw, t.data());
     for (int k = 0; k < w; ++k) tf[k] = make_float2((float)t[2 * k], (float)t[2 * k + 1]);
     CK(hipMalloc(&tw, w * sizeof(float2))); CK(hipMemcpy(tw, tf.data(), w * sizeof(float2), hipMemcpyHostToDevice));
-    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipStream_t sa, sb;
+    if (getenv("STX_EXP_PRIO")) {   // the stencil's stream ahead of the transforms' (1), or behind it (2)
+        int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        printf("priorities: least %d, greatest %d\n", lo, hi);
+        const bool first = atoi(getenv("STX_EXP_PRIO")) == 1;
+        CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, first ? hi : lo)); CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, first ? lo : hi));
+    } else { CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); }
     launch_synth(sa, bgr, 1, 0x5EED0002, 0, 0, F, h, w);
     BgrSource src = {bgr, 3 * w, (int64_t)3 * w * h, 15};
     auto stencil = [&](hipStream_t s, int which) {
@@ -94,5 +161,46 @@ int main(int argc, char** argv) {
     timed("stencil then rows", [&] { stencil(sa, 1); rows(sa, 0); });
     timed("stencil || rows (2 streams)", [&] { stencil(sa, 1); rows(sb, 0); });
     timed("rows || stencil (2 streams)", [&] { rows(sb, 0); stencil(sa, 1); });
+    {
+        const int nwg = 150000, per = 8;   // 150,000 x 8 KB = 1.23 GB
+        float* sink; CK(hipMalloc(&sink, 64));
+        float4* big = (float4*)spec;        // the spectrum buffer is at least that large at 1080p
+        if ((size_t)F * lay.nkb * g.fh * lay.cbw * sizeof(float2) < (size_t)nwg * per * 1024) { printf("spectrum too small for the diagnostics\n"); return 0; }
+        auto st = [&](hipStream_t s) { hipLaunchKernelGGL(store_only, dim3(nwg), dim3(64), 0, s, big, per); };
+        auto ld = [&](hipStream_t s) { hipLaunchKernelGGL(load_only, dim3(nwg), dim3(64), 0, s, big, sink, per); };
+        auto va = [&](hipStream_t s) { hipLaunchKernelGGL(valu_only, dim3(nwg), dim3(64), 0, s, sink, 900); };
+        timed("stores alone", [&] { st(sa); });
+        timed("non-temporal stores alone", [&] { hipLaunchKernelGGL(store_nt, dim3(nwg), dim3(64), 0, sa, big, per); });
+        timed("stores, 256-thread groups", [&] { hipLaunchKernelGGL(store_wg256, dim3(nwg / 4), dim3(256), 0, sa, big, per); });
+        {
+            const int n3 = 540 * (nwg / 540);   // whole groups of 540 row pairs
+            timed("full lines 540 apart", [&] { hipLaunchKernelGGL(store_lines<false>, dim3(n3), dim3(64), 0, sa, big, per, n3); });
+            timed("full lines 540 apart, nt", [&] { hipLaunchKernelGGL(store_lines<true>, dim3(n3), dim3(64), 0, sa, big, per, n3); });
+            timed("half lines twice", [&] { hipLaunchKernelGGL(store_halves<false>, dim3(n3), dim3(64), 0, sa, (float2*)big, 2 * per, n3); });
+            timed("half lines twice, nt", [&] { hipLaunchKernelGGL(store_halves<true>, dim3(n3), dim3(64), 0, sa, (float2*)big, 2 * per, n3); });
+        }
+        timed("hipMemsetAsync", [&] { (void)hipMemsetAsync(big, 1, (size_t)nwg * per * 1024, sa); });
+        timed("non-temporal loads alone", [&] { hipLaunchKernelGGL(load_nt, dim3(nwg), dim3(64), 0, sa, big, sink, per); });
+        timed("stencil || stores", [&] { stencil(sa, 1); st(sb); });
+        timed("loads alone", [&] { ld(sa); });
+        timed("stencil || loads", [&] { stencil(sa, 1); ld(sb); });
+        timed("valu alone", [&] { va(sa); });
+        timed("stencil || valu", [&] { stencil(sa, 1); va(sb); });
+        for (int per_cu : {4, 8, 16}) {   // the same neighbours as grids of a few long-lived waves per compute unit
+            const int n2 = 256 * per_cu, per2 = (int)((size_t)nwg * per / n2);
+            auto st2 = [&](hipStream_t s) { hipLaunchKernelGGL(store_only, dim3(n2), dim3(64), 0, s, big, per2); };
+            auto ld2 = [&](hipStream_t s) { hipLaunchKernelGGL(load_only, dim3(n2), dim3(64), 0, s, big, sink, per2); };
+            auto va2 = [&](hipStream_t s) { hipLaunchKernelGGL(valu_only, dim3(n2), dim3(64), 0, s, sink, 900 * (nwg / n2) / 4); };
+            printf("neighbour: %d long-lived waves per compute unit\n", per_cu);
+            timed("  stores alone", [&] { st2(sa); });
+            timed("  stores, then stencil queued", [&] { st2(sb); stencil(sa, 1); });
+            timed("  loads alone", [&] { ld2(sa); });
+            timed("  loads, then stencil queued", [&] { ld2(sb); stencil(sa, 1); });
+            timed("  valu alone", [&] { va2(sa); });
+            timed("  valu, then stencil queued", [&] { va2(sb); stencil(sa, 1); });
+        }
+        timed("rows || valu", [&] { rows(sa, 0); va(sb); });
+        timed("rows || loads", [&] { rows(sa, 0); ld(sb); });
+    }
     return 0;
 }
