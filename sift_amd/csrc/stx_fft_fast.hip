@@ -549,7 +549,7 @@ struct RowsArgs {
 #else
 #define STX_ROWS_ATTR
 #endif
-template <class P, bool DIRECT>
+template <class P, bool DIRECT, bool STAGED>
 __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
     constexpr int N = P::N, LPT = P::LPT;
     constexpr bool PAIRS = (LPT == 64);  // fused last pass
@@ -564,7 +564,8 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
     constexpr int HALF8 = (N / 2 + 1 + 7) / 8 * 8;
     constexpr int STAGE_B = HALF8 + ((16 - HALF8 % 32) + 32) % 32;
     constexpr int STAGE = STAGE_B + HALF8;
-    constexpr int LDS_ELEMS = (PAIRS && STAGE > P::S) ? STAGE : P::TPW * P::S;
+    static_assert(!STAGED || PAIRS, "the staged output is the fused last pass's");
+    constexpr int LDS_ELEMS = (STAGED && STAGE > P::S) ? STAGE : P::TPW * P::S;
     __shared__ __attribute__((aligned(16))) float2 lds[LDS_ELEMS];
     constexpr bool PREFETCH = !DIRECT && (N % 4 == 0);
     constexpr int NL = DIRECT ? P::R0 : (PREFETCH ? (N / 4 + LPT - 1) / LPT : 1);  // loads per lane and row
@@ -709,9 +710,8 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
         // address is wave-uniform (folded into the base pointer); the bin part depends on the lane only,
         // so it stays a 32-bit offset that does not change from unit to unit.
         float2* base = a.spec + (int64_t)frame * a.nkb * a.fh * cbw + ((int64_t)ra << a.cbw_log2);
-        const bool staged = PAIRS && cbw == 8;
         auto emit = [&](int k, float2 zk, float2 zc) {
-            if (PAIRS && staged) {
+            if constexpr (STAGED) {
                 buf[k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
                 buf[STAGE_B + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
             } else if (ina) {
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
                 settle_prefetch();
                 last_pass_pairs<P, P::R3>(buf, tw_last, t, emit);
             }
-            if (staged) {
+            if constexpr (STAGED) {
                 wave_sync();  // the bins were parked by other lanes
                 constexpr int NBLK = HALF8 / 8;
                 const int g = lane >> 3, l = lane & 7;
@@ -1036,14 +1036,22 @@ void launch_rows_t(hipStream_t s, RowsArgs a, int n_frames) {
         const int grid = a.total_units < 256 * per_cu ? a.total_units : 256 * per_cu;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, a);
     };
+    // whole-line stores: one transform per wave and column blocks of eight bins (two rows of a block = 128 bytes)
+    const bool staged = P::LPT == 64 && a.cbw == 8;
     if constexpr (Direct<P>::ok) {
         // narrow loads need B-byte aligned rows: gray rows start 4-byte aligned, the crop origin decides
         if ((a.fox & 3) == 0 && (a.gpitch & 3) == 0) {
-            launch(rows_kernel<P, true>);
+            if constexpr (P::LPT == 64) {
+                if (staged) { launch(rows_kernel<P, true, true>); return; }
+            }
+            launch(rows_kernel<P, true, false>);
             return;
         }
     }
-    launch(rows_kernel<P, false>);
+    if constexpr (P::LPT == 64) {
+        if (staged) { launch(rows_kernel<P, false, true>); return; }
+    }
+    launch(rows_kernel<P, false, false>);
 }
 
 template <class P>
