@@ -644,8 +644,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
                        (const uint8_t*)c->tie.p, (uint8_t*)sl.tflag.p + (size_t)F * g.bm_tiles * g.bm_words, sl.raw);
         sp.end();
     }
-    // (a raw chunk's second-stream work waits for the row pass instead: no event between the stencil and the row pass)
-    if (!(sl.raw && fused_flow) || c->streaming) HIPCHK(c, hipEventRecord(sl.stencil_done, s));
+    HIPCHK(c, hipEventRecord(sl.stencil_done, s));
     if (!lbp81) {
         Span sp(c, &sl.spans, STX_K_LBP_GENERIC, 2, s);
         const bool ok = launch_lbp_generic(s, (const uint8_t*)sl.gray.p, F, g, p.lbp_points, pr.off, (uint32_t*)sl.lpart.p, acc,
@@ -677,13 +676,12 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
     // back to back with no event between them; the hysteresis passes, which leave the device mostly idle, run on the
     // second stream beside the row pass, and so does the collection of the results, beside the next chunk's stencil
     // pass.
-    // A raw chunk's floods and suppression start when the row pass is done, and run beside the column pass: beside the
-    // row pass -- a persistent grid at its HBM-store bound -- the first flood takes 0.3 ms and costs the row pass 0.04 ms;
-    // the column pass gives up 0.025 ms for all of it (1.354 -> 1.32 ms per clip).
-    const bool after_rows = fused_flow && sl.raw;
+    // A raw chunk's floods and suppression start there too.  (While the row pass was bound by its half-line stores they
+    // waited for it to finish: beside it the first flood took 0.3 ms and cost it 0.04 ms.  Storing whole lines, the row
+    // pass gives up 0.012 ms for them and the column pass gets 0.034 ms back: 1.231 -> 1.216 ms per clip.)
     auto queue_side = [&]() -> int {
         hipStream_t hs = fused_flow ? side : s;
-        if (fused_flow) HIPCHK(c, hipStreamWaitEvent(side, after_rows ? sl.gray_ready : sl.stencil_done, 0));
+        if (fused_flow) HIPCHK(c, hipStreamWaitEvent(side, sl.stencil_done, 0));
         if (sl.raw) {
             // flood of the raw maps (its own pass flags), suppression on what it reached; the ordinary passes then
             // start from pass 0 on the suppressed maps
@@ -705,7 +703,7 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
         if ((rc = hyst_passes(c, sl, sl.raw ? RAW_SECOND_PASSES : HYST_FIRST_PASSES, g, hs)) != STX_OK) return rc;
         return STX_OK;
     };
-    if (!after_rows && (rc = queue_side()) != STX_OK) return rc;
+    if ((rc = queue_side()) != STX_OK) return rc;
     {
         hipStream_t sf = fused_gray ? s : side;
         if (sf != s) HIPCHK(c, hipStreamWaitEvent(sf, sl.gray_ready, 0));
@@ -713,10 +711,6 @@ int enqueue_chunk(stx_ctx* c, Slot& sl, const uint8_t* bgr_dev, int64_t row_stri
             Span sp(c, &sl.spans, STX_K_FFT_ROWS, 1, sf);
             launch_fft_rows(sf, (const uint8_t*)sl.gray.p, F, g, lay, pr.plan_w, pr.tw_w, (float2*)sl.spec.p);
             sp.end();
-        }
-        if (after_rows) {  // (gray_ready is free again by now: the stencil pass has been queued behind it)
-            HIPCHK(c, hipEventRecord(sl.gray_ready, sf));
-            if ((rc = queue_side()) != STX_OK) return rc;
         }
         {
             Span sp(c, &sl.spans, STX_K_FFT_COLS, 1, sf);
