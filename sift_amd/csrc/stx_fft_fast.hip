@@ -728,19 +728,20 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
                 pass<P::N, P::R0, 1, P::LPT, P::SWZ>(buf, a.tw, t, st);
             }
             if constexpr (NP == 2) {
-                settle_prefetch();
+                if constexpr (!STAGED) settle_prefetch();
                 last_pass_pairs<P, P::R1>(buf, tw_last, t, emit);
             } else if constexpr (NP == 3) {
                 pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
-                settle_prefetch();
+                if constexpr (!STAGED) settle_prefetch();
                 last_pass_pairs<P, P::R2>(buf, tw_last, t, emit);
             } else {
                 pass<P::N, P::R1, P::R0, P::LPT, P::SWZ>(buf, tw_p1, t, st);
                 pass<P::N, P::R2, P::R0 * P::R1, P::LPT, P::SWZ>(buf, tw_p2, t, st);
-                settle_prefetch();
+                if constexpr (!STAGED) settle_prefetch();
                 last_pass_pairs<P, P::R3>(buf, tw_last, t, emit);
             }
             if constexpr (STAGED) {
+                settle_prefetch();  // (here the stores go out after the last pass: the prefetch has had that long as well)
                 wave_sync();  // the bins were parked by other lanes
                 constexpr int NBLK = HALF8 / 8;
                 const int g = lane >> 3, l = lane & 7;
