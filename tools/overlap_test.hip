@@ -158,6 +158,7 @@ int main(int argc, char** argv) {
     });
     timed("stencil alone", [&] { stencil(sa, 1); });
     timed("rows alone", [&] { rows(sa, 0); });
+    timed("columns alone", [&] { cols(sa, 0); });
     timed("stencil then rows", [&] { stencil(sa, 1); rows(sa, 0); });
     timed("stencil || rows (2 streams)", [&] { stencil(sa, 1); rows(sb, 0); });
     timed("rows || stencil (2 streams)", [&] { rows(sb, 0); stencil(sa, 1); });
