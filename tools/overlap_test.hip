@@ -156,6 +156,9 @@ int main(int argc, char** argv) {
             cols(sb, b);
         }
     });
+    timed("rows then columns", [&] { rows(sa, 0); cols(sa, 0); });
+    timed("rows || columns (2 streams)", [&] { rows(sa, 0); cols(sb, 0); });
+    timed("columns || rows (2 streams)", [&] { cols(sb, 0); rows(sa, 0); });
     timed("stencil alone", [&] { stencil(sa, 1); });
     timed("rows alone", [&] { rows(sa, 0); });
     timed("columns alone", [&] { cols(sa, 0); });
