@@ -1,6 +1,15 @@
-// Experiment: how much of the FFT row pass (bound by HBM stores) hides beside the stencil pass (bound by vector issue)
-// when the two run at the same time on two streams -- with the row kernel as built, and with it held to 128 registers
-// so that its waves fit beside the stencil's.  Links the library's object files.
+// Experiments on what the big kernels of the path do to each other and to the memory system, on the library's own
+// kernels (links its object files):
+//   * the stencil pass, the FFT row pass and the FFT column pass alone, back to back and on two streams (stream
+//     priorities with STX_EXP_PRIO=1|2), a run of 24 clips on one stream and with the stencil of clip k+1 beside the
+//     FFT pair of clip k;
+//   * the stencil pass beside kernels that only store, only load or only issue vector instructions, as ordinary grids
+//     of one-wave workgroups and as grids of a few long-lived waves per compute unit;
+//   * what a 1.2 GB store or load stream reaches by shape: contiguous, non-temporal, whole 128-byte lines far apart,
+//     half lines written by two instructions, hipMemsetAsync.
+// (The runs with the stencil held to two or three workgroups per compute unit, and the row pass held to a few waves
+// per compute unit, were made with a dynamic-LDS reservation on the stencil's launch and a grid-size override in the
+// row pass's launcher, neither of which is in the library.)
 //   usage: overlap_test <h> <w> <frames>
 #include <stdio.h>
 #include <stdlib.h>
