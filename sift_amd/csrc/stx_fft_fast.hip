@@ -717,8 +717,10 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
             } else if (ina) {
                 const uint32_t off = ((((uint32_t)k >> a.cbw_log2) * (uint32_t)a.fh) << a.cbw_log2) + ((uint32_t)k & (uint32_t)(cbw - 1));
                 float2* o = base + off;
-                o[0] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-                if (inb) o[cbw] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+                const float2 va = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+                const float2 vb = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+                o[0] = va;
+                if (inb) o[cbw] = vb;
             }
         };
         if constexpr (PAIRS) {
@@ -765,7 +767,39 @@ __global__ __launch_bounds__(64) STX_ROWS_ATTR void rows_kernel(RowsArgs a) {
             }
             settle_prefetch();
             // split the packed transform: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
-            for (int k = t; k <= N / 2; k += LPT) emit(k, buf[pad<P::SWZ>(k)], buf[pad<P::SWZ>(k ? N - k : 0)]);
+            if (cbw == 16) {
+                // Column blocks of sixteen bins: a row of a block is one 128-byte line, and the wave's 2*TPW image rows
+                // are neighbours in every block.  Eight lanes write one row's line, sixteen bytes (two bins) each, so
+                // one instruction per block covers all the wave's rows -- 1 KB in one piece at TPW = 4 -- instead of
+                // two instructions of alternate lines; every lane splits the two bins of ITS row (either the a or
+                // the b row of a pair) from the pair's transform in LDS.
+                const int row = lane >> 3, col2 = 2 * (lane & 7);
+                const bool second = (row & 1) != 0;
+                const float2* zb = lds + (row >> 1) * P::S;
+                const int ra0 = ra - 2 * sub;  // the first image row of the wave's group (wave-uniform)
+                const bool row_ok = row < 2 * P::TPW && ra0 + row < a.fh;
+                float4* gp = reinterpret_cast<float4*>(a.spec + (int64_t)frame * a.nkb * a.fh * 16 + (int64_t)(ra0 + row) * 16 + col2);
+                for (int kb = 0; kb * 16 <= N / 2; ++kb) {
+                    const int k0 = 16 * kb + col2;
+                    if (row_ok && k0 <= N / 2) {
+                        float2 o2[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int k = k0 + j;
+                            o2[j] = make_float2(0.f, 0.f);
+                            if (k <= N / 2) {
+                                const float2 zk = zb[pad<P::SWZ>(k)], zc = zb[pad<P::SWZ>(k ? N - k : 0)];
+                                o2[j] = second ? make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x))
+                                               : make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+                            }
+                        }
+                        const f4v v = {o2[0].x, o2[0].y, o2[1].x, o2[1].y};
+                        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(gp + (int64_t)kb * a.fh * 8));
+                    }
+                }
+            } else {
+                for (int k = t; k <= N / 2; k += LPT) emit(k, buf[pad<P::SWZ>(k)], buf[pad<P::SWZ>(k ? N - k : 0)]);
+            }
         }
         wave_sync();  // the next unit's signal overwrites what other lanes have just read
     }

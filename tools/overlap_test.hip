@@ -183,6 +183,12 @@ int main(int argc, char** argv) {
         auto ld = [&](hipStream_t s) { hipLaunchKernelGGL(load_only, dim3(nwg), dim3(64), 0, s, big, sink, per); };
         auto va = [&](hipStream_t s) { hipLaunchKernelGGL(valu_only, dim3(nwg), dim3(64), 0, s, sink, 900); };
         timed("stores alone", [&] { st(sa); });
+        {
+            float4* fresh; CK(hipMalloc(&fresh, (size_t)nwg * per * 1024));
+            timed("stores alone, a buffer nothing else has touched", [&] { hipLaunchKernelGGL(store_only, dim3(nwg), dim3(64), 0, sa, fresh, per); });
+            timed("the same on the null stream", [&] { hipLaunchKernelGGL(store_only, dim3(nwg), dim3(64), 0, 0, fresh, per); (void)hipStreamSynchronize(0); });
+            CK(hipFree(fresh));
+        }
         timed("non-temporal stores alone", [&] { hipLaunchKernelGGL(store_nt, dim3(nwg), dim3(64), 0, sa, big, per); });
         timed("stores, 256-thread groups", [&] { hipLaunchKernelGGL(store_wg256, dim3(nwg / 4), dim3(256), 0, sa, big, per); });
         {
