@@ -56,3 +56,18 @@ def test_row_pairs_with_an_odd_height(ctx, hw):
     r = ctx.analyze_frames([b for _, b in frames])
     for (g, _), m in zip(frames, r):
         assert m.frequency_anomaly == pytest.approx(_ref(g), rel=1e-5), hw
+
+
+@pytest.mark.parametrize("hw", [(540, 256), (540, 128), (540, 96), (360, 160), (540, 64)])
+def test_sub_wave_rows_on_sixteen_bin_blocks(ctx, hw):
+    """Row transforms that share a wave (widths up to 256) write all their rows of a sixteen-bin column block with one
+    instruction; 540 rows leave the last wave of a frame with half of its row pairs."""
+    h, w = hw
+    rng = np.random.default_rng(h * 4096 + w)
+    frames = []
+    for _ in range(3):
+        g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        frames.append((g, np.ascontiguousarray(np.repeat(g[..., None], 3, axis=2))))
+    r = ctx.analyze_frames([b for _, b in frames])
+    for (g, _), m in zip(frames, r):
+        assert m.frequency_anomaly == pytest.approx(_ref(g), rel=1e-5), hw
